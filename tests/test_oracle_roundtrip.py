@@ -1,0 +1,137 @@
+"""Oracle encode -> decode round trips on the inputs of the reference's own encoder tests
+(tests/format.rs): this is exactly how the reference validates its encoder."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _pcm import generate_sine_1, generate_sine_2, read_raw, synth
+
+
+def roundtrip(opts, rate, bps, ch, pcm, total_known=True, threads=1):
+    rc, data, st = orc.encode_stream(opts, rate, bps, ch, pcm, total_known=total_known,
+                                     threads=threads)
+    assert rc == 0, rc
+    rc2, out, info = orc.decode_stream(data)
+    assert rc2 == 0, rc2
+    n = pcm.size - pcm.size % ch
+    assert np.array_equal(out, pcm[:n])
+    assert info.md5_ok == 1
+    assert (info.sample_rate, info.channels, info.bps) == (rate, ch, bps)
+    assert info.total_samples == n // ch
+    assert info.min_frame == st.min_frame_size and info.max_frame == st.max_frame_size
+    return data, st, info
+
+
+def test_small_files():  # tests/format.rs:16-82
+    opts = orc.options("fast", max_lpc_order=16, mid_side=1, padding=-1)
+    for ch in (1, 2):
+        for n in range(1, 11):
+            pcm = (np.arange(n * ch, dtype=np.int32) * 37 - 100).astype(np.int32)
+            roundtrip(opts, 44100, 16, ch, pcm)
+
+
+@pytest.mark.parametrize("lpc", [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32])
+def test_blocksize_variations(lpc):  # tests/format.rs:84-134
+    pcm = read_raw("noise32.raw", 8)
+    for bs in range(16, 34):
+        opts = orc.options("best", block_size=bs, max_lpc_order=lpc)
+        rc, data, _ = orc.encode_stream(opts, 44100, 8, 1, pcm)
+        assert rc == 0
+        rc2, out, info = orc.decode_stream(data)
+        # (quirk Q8, SURVEY.md A.7, is not reachable on this input: the reference's own test
+        # passes for every one of these combinations, and so must the oracle)
+        assert rc2 == 0
+        assert np.array_equal(out, pcm)
+        assert info.md5_ok == 1
+
+
+@pytest.mark.parametrize("bs,total", [(33, 31), (33, 33), (33, 35), (256, 254), (256, 256),
+                                      (256, 258), (2048, 2046), (2048, 2048), (2048, 2050),
+                                      (4608, 4606), (4608, 4608), (4608, 4610), (4608, 9218)])
+def test_fractional(bs, total):  # tests/format.rs:136-205
+    noise = read_raw("noise-256k.raw", 16)
+    opts = orc.options("default", block_size=bs)
+    roundtrip(opts, 44100, 16, 2, noise[: total * 2])
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4, 8])
+@pytest.mark.parametrize("bps", [8, 16, 24])
+@pytest.mark.parametrize("n", [1, 111, 4777])
+def test_roundtrip_files(ch, bps, n):  # tests/format.rs:207-435
+    pcm = read_raw(f"roundtrip-{ch}-{bps}-{n}.raw", bps)
+    assert pcm.size == ch * n
+    opts = orc.options("default", padding=-1)
+    roundtrip(opts, 44100, bps, ch, pcm)
+
+
+@pytest.mark.parametrize("bps", [8, 16, 24, 32])
+def test_full_scale_deflection(bps):  # tests/format.rs:437-621
+    hi, lo = (1 << (bps - 1)) - 1, -(1 << (bps - 1))
+    pats = [[0, hi], [0, lo], [hi, lo], [hi, hi, lo, lo], [lo, hi, hi, lo, 0, hi, lo]]
+    opts = orc.options("default")
+    for p in pats:
+        pcm = np.array((p * 1200)[:4800], dtype=np.int64).astype(np.int32)
+        roundtrip(opts, 44100, bps, 1, pcm)
+        if bps < 32 or True:
+            roundtrip(opts, 44100, bps, 2, pcm)
+
+
+def test_wasted_bits():  # tests/format.rs:623-685
+    pcm = read_raw("wasted-bits.raw", 16)
+    opts = orc.options("default")
+    roundtrip(opts, 44100, 16, 1, pcm)
+    planar = pcm[:2000].reshape(1, -1)
+    rc, _, plan = orc.encode_frame(opts, 44100, 16, planar)
+    assert rc == 0 and plan.sub[0].wasted > 0
+
+
+@pytest.mark.parametrize("bps", [8, 16, 24, 32])
+@pytest.mark.parametrize("rate", [44100, 48000, 96000])
+def test_sine_wave_streams(bps, rate):  # tests/format.rs:776-1004 (shape)
+    fs = float((1 << (bps - 1)) - 1)
+    n = 20000
+    opts = orc.options("default")
+    roundtrip(opts, rate, bps, 1, generate_sine_1(fs, rate, n, 441.0, 0.5 * 0, 441.0, 0.5))
+    roundtrip(opts, rate, bps, 2, generate_sine_2(fs, rate, n, 441.0, 0.3 * 0, 4410.0, 0.1, 1.3))
+
+
+@pytest.mark.parametrize("preset", ["default", "fast", "best"])
+@pytest.mark.parametrize("ch,bps", [(1, 8), (2, 16), (4, 24), (8, 32), (2, 24), (2, 32)])
+def test_noise(preset, ch, bps):  # tests/format.rs:1248-1384
+    rng = np.random.Generator(np.random.PCG64(ch * 100 + bps))
+    lo, hi = -(1 << (bps - 1)), (1 << (bps - 1))
+    pcm = rng.integers(lo, hi, size=ch * 10000, dtype=np.int64).astype(np.int32)
+    for bs in (None, 32, 4096):
+        opts = orc.options(preset) if bs is None else orc.options(preset, block_size=bs)
+        roundtrip(opts, 44100, bps, ch, pcm)
+
+
+def test_total_unknown_inserts_seektable_after_padding():  # encode.rs:2053-2073
+    pcm = synth(1, 2, 16, 9000)
+    opts = orc.options("default")
+    data, st, info = roundtrip(opts, 44100, 16, 2, pcm, total_known=False)
+    assert info.n_seekpoints == 1  # 9000 samples < 10 s: only the point containing sample 0
+    # STREAMINFO, PADDING (shrunk by the 22-byte SEEKTABLE), SEEKTABLE(last)
+    assert data[42] & 0x7F == 1 and int.from_bytes(data[43:46], "big") == 4096 - 22
+    assert st.first_frame_offset == 4 + 38 + 4 + 4096
+
+
+def test_frame_parallel_matches_sequential():
+    pcm = synth(2, 2, 24, 4096 * 5 + 123)
+    opts = orc.options("best")
+    a = orc.encode_stream(opts, 48000, 24, 2, pcm)[1]
+    b = orc.encode_stream(opts, 48000, 24, 2, pcm, threads=4)[1]
+    assert a == b and len(a) > 0
+
+
+def test_error_paths():
+    o = orc.options("default")
+    z = np.zeros(10, dtype=np.int32)
+    assert orc.encode_stream(o, 44100, 0, 1, z)[0] == -1      # InvalidBitsPerSample
+    assert orc.encode_stream(o, 44100, 33, 1, z)[0] == -1
+    assert orc.encode_stream(o, 1 << 20, 16, 1, z)[0] == -2   # InvalidSampleRate
+    assert orc.encode_stream(o, 44100, 16, 9, z)[0] == -3     # ExcessiveChannels
+    assert orc.encode_stream(o, 44100, 16, 3, z)[0] == -4     # SamplesNotDivisibleByChannels
+    assert orc.encode_stream(orc.options("default", block_size=15), 44100, 16, 1, z)[0] == -10
