@@ -1,0 +1,117 @@
+"""ctypes loader for libflacenc_amd.so (the C-ABI shared library of this package).
+
+The library holds the hand-written gfx950 kernels; there is NO CPU fallback: if it is
+missing or fails to load, importing anything that needs it raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflacenc_amd.so")
+
+MAX_CHANNELS = 8
+MAX_LPC_ORDER = 32
+MAX_PARTITIONS = 64
+N_KERNELS = 10
+
+
+class GpuOptions(C.Structure):
+    """flacgpu_options (include/flacenc_gpu.h)."""
+    _fields_ = [
+        ("block_size", C.c_uint32),
+        ("max_partition_order", C.c_uint32),
+        ("max_lpc_order", C.c_uint32),
+        ("mid_side", C.c_uint8),
+        ("exhaustive_channel_correlation", C.c_uint8),
+        ("window_kind", C.c_uint8),
+        ("reserved", C.c_uint8),
+        ("window_param", C.c_float),
+    ]
+
+
+class SubframePlan(C.Structure):
+    """flacgpu_subframe_plan."""
+    _fields_ = [
+        ("type", C.c_uint8),
+        ("wasted", C.c_uint8),
+        ("bps", C.c_uint8),
+        ("order", C.c_uint8),
+        ("precision", C.c_uint8),
+        ("shift", C.c_uint8),
+        ("coding_method", C.c_uint8),
+        ("partition_order", C.c_uint8),
+        ("source", C.c_uint8),
+        ("reserved", C.c_uint8 * 3),
+        ("n_partitions", C.c_uint32),
+        ("part_len", C.c_uint32),
+        ("bits", C.c_uint32),
+        ("coeffs", C.c_int32 * MAX_LPC_ORDER),
+        ("rice", C.c_uint8 * MAX_PARTITIONS),
+        ("escape_bits", C.c_uint8 * MAX_PARTITIONS),
+    ]
+
+
+class FramePlan(C.Structure):
+    """flacgpu_frame_plan."""
+    _fields_ = [
+        ("assignment", C.c_uint8),
+        ("channels", C.c_uint8),
+        ("block_size", C.c_uint16),
+        ("body_bits", C.c_uint32),
+    ]
+
+
+class GpuStats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint32),
+        ("lpc_failed", C.c_uint32),
+        ("order_ties", C.c_uint32),
+        ("log2_edge", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libflacenc_amd.so.  Fails loudly when the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    ip = C.POINTER(C.c_int32)
+    L.flacgpu_create.argtypes = [C.POINTER(GpuOptions), C.c_uint32, C.c_uint32, C.c_int,
+                                 C.c_uint32, C.POINTER(vp)]
+    L.flacgpu_destroy.argtypes = [vp]
+    L.flacgpu_destroy.restype = None
+    L.flacgpu_last_error.restype = C.c_char_p
+    L.flacgpu_analyze.argtypes = [vp, ip, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(FramePlan),
+                                  C.POINTER(SubframePlan), ip]
+    L.flacgpu_analyze_device.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp]
+    L.flacgpu_fetch.argtypes = [vp, C.POINTER(FramePlan), C.POINTER(SubframePlan), ip]
+    L.flacgpu_get_stats.argtypes = [vp, C.POINTER(GpuStats)]
+    L.flacgpu_device_buffer.argtypes = [vp, C.c_int]
+    L.flacgpu_device_buffer.restype = vp
+    L.flacgpu_set_timing.argtypes = [vp, C.c_int]
+    L.flacgpu_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * N_KERNELS)]
+    L.flacgpu_kernel_name.argtypes = [C.c_int]
+    L.flacgpu_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names of the dynamic symbols the shared library exports (for the ABI test)."""
+    import subprocess
+
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB_PATH], text=True)
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}

@@ -1,0 +1,1520 @@
+// flacenc_gpu.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the FLAC encode hot path.
+//
+// Written for gfx950 only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see csrc/Makefile).
+// -ffp-contract=off is REQUIRED: the f64 analysis must round exactly like the
+// reference (Rust never contracts a*b+c; it uses mul_add only where written).
+//
+// Kernel inventory (reference function each one replaces, /root/reference/src):
+//   K0 k_deinterleave  audio.rs:190-199  Frame::fill_from_samples
+//   K1 k_stereo_stats  encode.rs:2463-2674 correlate_channels (fast mode only)
+//   K2 k_fixed         encode.rs:2849-2898 (wasted bits), 3020-3088 encode_fixed_subframe,
+//                      3747-3962 write_residuals' search (exact bit count instead of recording)
+//   K3 k_autocorr      encode.rs:1785-1801 Window::apply + 3478-3501 autocorrelate
+//                      (exact reference summation order: one sequential f64 chain per lag)
+//   K4 k_lpc           encode.rs:3536-3580 lp_coefficients, 3656-3702 compute_best_order,
+//                      3334-3401 quantize
+//   K5 k_fir           encode.rs:3174-3203 encode_residuals + write_residuals' search +
+//                      2929-2979 fixed/LPC/verbatim choice
+//   K6 k_decide        encode.rs:2747-2786 / 2803-2835 channel-assignment choice
+//   K7 k_emit          residual signal of the chosen subframes (FIR / fixed), the data
+//                      `BitRecorder::playback` would replay
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "flacenc_gpu.h"
+
+namespace {
+
+constexpr int WG = 256;          // threads per workgroup (4 wave64)
+constexpr int MAXP = 6;          // max effective partition order (64 partitions, encode.rs:3756)
+constexpr int NLEAF = 1 << MAXP;
+constexpr int NNODE = 2 * NLEAF - 1;
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return FLACGPU_ERR_HIP;                                                     \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------
+// device-side records
+// ---------------------------------------------------------------------------------
+typedef flacgpu_subframe_plan SubPlan;  // same layout on both sides of the ABI
+
+struct CandInfo {        // per (frame, candidate)
+    uint8_t active;      // 0: not a candidate for this frame (fast correlation / no mid)
+    uint8_t wasted;
+    uint8_t bps;         // effective bps after wasted-bit removal
+    uint8_t is_const;    // all samples zero -> CONSTANT, nothing else to analyse
+};
+
+struct LpcParams {       // per (frame, candidate), output of k_lpc
+    int32_t status;      // 0 ok; else the reference's error (1 Insufficient, 2 NoBestOrder,
+                         // 3 ZeroCoeffs, 4 NegativeShift)
+    uint8_t order, precision, shift, pad;
+    int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+};
+
+struct FrameInfo {       // per frame, from k_stereo_stats (fast mode) -- preset assignment
+    uint8_t assignment;
+    uint8_t pad[3];
+};
+
+struct Params {
+    // stream shape / options
+    uint32_t channels, bps, block_size, ldb;      // ldb = row stride of the planar buffer
+    uint32_t ncand;                                // candidate slots per frame
+    uint32_t stereo4;                              // 1: slots are L,R,M,S
+    uint32_t mid_side, exhaustive;
+    uint32_t max_lpc_order, max_po, use_rice2;
+    uint32_t n_frames, last_len;
+    // buffers
+    const int32_t *planar;
+    const double *window_full, *window_last;
+    const double *log2_thr;                        // [128], index e + 64
+    CandInfo *cinfo;
+    SubPlan *fixed_plan, *cand_plan, *out_plan;
+    LpcParams *lpc;
+    double *ac;                                    // [n_frames*ncand][36]
+    FrameInfo *finfo;
+    flacgpu_frame_plan *frame_plan;
+    int32_t *residuals;                            // [n_frames][channels][block_size]
+    uint32_t *stats;                               // [4]
+};
+
+__device__ __forceinline__ uint32_t frame_len(const Params &p, uint32_t frame) {
+    return (frame + 1 == p.n_frames) ? p.last_len : p.block_size;
+}
+
+// XCD-aware (frame, candidate) <- blockIdx mapping: consecutive blockIdx values are dealt
+// round-robin over the 8 XCDs, so put the candidates of one frame 8 blocks apart: they
+// then share an XCD L2 and the frame's L/R rows are fetched from HBM once.
+__device__ __forceinline__ void map_block(uint32_t bid, uint32_t nc, uint32_t nframes,
+                                          uint32_t &frame, uint32_t &cand) {
+    uint32_t full = nframes / 8u;
+    uint32_t per = 8u * nc;
+    if (bid < full * per) {
+        uint32_t g = bid / per, rem = bid - g * per;
+        cand = rem / 8u;
+        frame = g * 8u + (rem & 7u);
+    } else {
+        uint32_t rem = bid - full * per, tail = nframes - full * 8u;
+        cand = rem / tail;
+        frame = full * 8u + (rem - cand * tail);
+    }
+}
+
+// candidate -> source rows.  mode 0: a;  1: (a+b)>>1 (mid);  2: a-b (side)
+struct CandSrc {
+    const int32_t *a, *b;
+    int mode;
+    uint32_t bps;
+    uint8_t source;
+};
+__device__ __forceinline__ CandSrc cand_src(const Params &p, uint32_t frame, uint32_t cand) {
+    CandSrc s;
+    const int32_t *base = p.planar + (size_t)frame * p.channels * p.ldb;
+    s.bps = p.bps;
+    if (p.stereo4 && cand >= 2) {
+        s.a = base;
+        s.b = base + p.ldb;
+        if (cand == 2) {
+            s.mode = 1;
+            s.source = FLACGPU_SRC_MID;
+        } else {
+            s.mode = 2;
+            s.bps = p.bps + 1;
+            s.source = FLACGPU_SRC_SIDE;
+        }
+    } else {
+        s.a = base + (size_t)cand * p.ldb;
+        s.b = s.a;
+        s.mode = 0;
+        s.source = (uint8_t)cand;
+    }
+    return s;
+}
+__device__ __forceinline__ int32_t combine(int mode, int32_t a, int32_t b) {
+    // encode.rs:2721 `(l + r) >> 1`, :2734 `l - r` (i32, wrapping in release builds)
+    if (mode == 1) return (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+    if (mode == 2) return (int32_t)((uint32_t)a - (uint32_t)b);
+    return a;
+}
+
+// ---------------------------------------------------------------------------------
+// workgroup reductions (wave64 shuffles, then 4-way LDS combine)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+    return v;
+}
+// all threads get the result; `scratch` holds >= 4 u64
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *scratch) {
+    v = wave_sum_u64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+__device__ __forceinline__ uint32_t block_or_u32(uint32_t v, uint64_t *scratch) {
+    v = wave_or_u32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (uint32_t)(scratch[0] | scratch[1] | scratch[2] | scratch[3]);
+}
+
+__device__ __forceinline__ uint32_t uabs(int32_t v) {
+    return v < 0 ? 0u - (uint32_t)v : (uint32_t)v;  // i32::unsigned_abs
+}
+__device__ __forceinline__ uint32_t zigzag(int32_t s) {  // encode.rs:3845-3849
+    return ((uint32_t)s << 1) ^ (uint32_t)(s >> 31);
+}
+
+// ---------------------------------------------------------------------------------
+// Rice partition search (encode.rs:3865-3896 best_partitions + 3765-3831 Partition::new)
+// and exact residual-block bit count (replaces BitRecorder::written()).
+// Cooperative over the workgroup.  `r` is indexed by SAMPLE POSITION: residual of sample i
+// lives at r[i], valid for i in [order, n).  Partitions are the reference's
+// `residuals.rchunks(n >> porder).rev()`, i.e. cuts at multiples of the partition length.
+// The f64 `ceil(log2(sum / n))` of encode.rs:3778-3780 is replaced by its exact integer
+// equivalent (smallest k with n * 2^k >= sum; valid because sum < 2^53).
+// ---------------------------------------------------------------------------------
+struct RiceShared {
+    unsigned long long leaf[NLEAF];
+    uint32_t nd_est[NNODE], nd_cnt[NNODE];
+    uint8_t nd_kind[NNODE], nd_rice[NNODE], nd_esc[NNODE], nd_valid[NNODE];
+    uint32_t lv_est[MAXP + 1], lv_count[MAXP + 1];
+    uint8_t lv_valid[MAXP + 1];
+    int32_t best_p;        // -1: fallback (single 31-bit escaped partition)
+    uint32_t best_count, method;
+    uint64_t red[4];
+};
+enum { PK_STANDARD = 0, PK_ESCAPED = 1, PK_CONSTANT = 2 };
+
+__device__ void rice_search(const int32_t *r, uint32_t n, uint32_t order, const Params &p,
+                            RiceShared &S, SubPlan &plan /* LDS */, uint32_t &resid_bits) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
+    uint32_t tz = (uint32_t)__builtin_ctz(n);
+    uint32_t P = tz < p.max_po ? tz : p.max_po;
+    if (P > MAXP) P = MAXP;  // host rejects such calls; clamp defensively
+    const uint32_t leaf_len = n >> P;
+    const uint32_t ept = (n + WG - 1) / WG;
+    const uint32_t lo = tid * ept;
+    const uint32_t hi = (lo + ept < n) ? lo + ept : n;
+
+    if (tid < NLEAF) S.leaf[tid] = 0ull;
+    __syncthreads();
+    {
+        uint32_t i = lo > order ? lo : order;
+        if (i < hi) {
+            uint32_t cur = i / leaf_len;
+            uint32_t bound = (cur + 1) * leaf_len;
+            unsigned long long acc = 0;
+            for (; i < hi; i++) {
+                if (i == bound) {
+                    atomicAdd(&S.leaf[cur], acc);
+                    acc = 0;
+                    cur++;
+                    bound += leaf_len;
+                }
+                acc += uabs(r[i]);
+            }
+            atomicAdd(&S.leaf[cur], acc);
+        }
+    }
+    __syncthreads();
+    // one thread per node of the partition tree: node id = 2^p + j  (1-based heap numbering)
+    if (tid < (2u << P) - 1u) {
+        uint32_t node = tid + 1;
+        uint32_t lvl = 31u - (uint32_t)__builtin_clz(node);
+        uint32_t j = node - (1u << lvl);
+        uint32_t plen = n >> lvl;
+        uint32_t start = j * plen, end = start + plen;
+        uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
+        uint32_t span = 1u << (P - lvl);
+        unsigned long long sum = 0;
+        for (uint32_t q = 0; q < span; q++) sum += S.leaf[j * span + q];
+        uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0, valid = 1;
+        uint32_t est = 0;
+        if (cnt > 0 && sum > 0) {
+            uint32_t k = 0;
+            bool standard = true;
+            if (sum > (unsigned long long)cnt) {
+                unsigned long long q = (sum + cnt - 1) / cnt;  // ceil(sum / cnt) >= 2
+                k = 64u - (uint32_t)__clzll((long long)(q - 1));
+                if (k >= rice_max) {
+                    standard = false;
+                    uint32_t e = (63u - (uint32_t)__clzll((long long)sum)) + 2u;  // ilog2(sum)+2
+                    if (e > 31u) valid = 0;
+                    kind = PK_ESCAPED;
+                    esc = (uint8_t)e;
+                    est = e * cnt;
+                }
+            }
+            if (standard) {
+                unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
+                if (t > 0xFFFFFFFFull) valid = 0;  // u32::try_from fails -> candidate dropped
+                kind = PK_STANDARD;
+                rice = (uint8_t)k;
+                est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
+            }
+        }
+        S.nd_kind[tid] = kind;
+        S.nd_rice[tid] = rice;
+        S.nd_esc[tid] = esc;
+        S.nd_valid[tid] = valid;
+        S.nd_est[tid] = est;
+        S.nd_cnt[tid] = cnt;
+    }
+    __syncthreads();
+    if (tid <= P) {
+        uint32_t lvl = tid, count = 0, est = 0;
+        bool ok = true;
+        for (uint32_t j = 0; j < (1u << lvl); j++) {
+            uint32_t nd = (1u << lvl) + j - 1u;
+            if (S.nd_cnt[nd] == 0) continue;  // chunk lies inside the warm-up: not a partition
+            count++;
+            if (!S.nd_valid[nd]) ok = false;
+            est += S.nd_est[nd];
+        }
+        // encode.rs:3881 `!p.is_empty() && p.len().is_power_of_two()`
+        S.lv_valid[lvl] = ok && count > 0 && (count & (count - 1)) == 0;
+        S.lv_est[lvl] = est;
+        S.lv_count[lvl] = count;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = -1;
+        for (uint32_t lvl = 0; lvl <= P; lvl++)
+            if (S.lv_valid[lvl] && (best < 0 || S.lv_est[lvl] < S.lv_est[best])) best = (int)lvl;
+        S.best_p = best;  // min_by_key: first minimum wins
+        S.best_count = best >= 0 ? S.lv_count[best] : 1u;
+        S.method = 0;
+    }
+    __syncthreads();
+    const int bp = S.best_p;
+    const uint32_t count = S.best_count;
+    const uint32_t first_j = bp >= 0 ? (1u << bp) - count : 0u;  // chunks inside warm-up skipped
+    if (bp >= 0) {
+        if (tid < count) {
+            uint32_t nd = (1u << bp) + first_j + tid - 1u;
+            plan.rice[tid] = S.nd_rice[nd];
+            plan.escape_bits[tid] = S.nd_esc[nd];
+            // try_reduce_rice, encode.rs:3929-3942: RICE2 only if some parameter >= 15
+            if (p.use_rice2 && S.nd_kind[nd] == PK_STANDARD && S.nd_rice[nd] >= 15)
+                atomicOr(&S.method, 1u);
+        }
+    } else if (tid == 0) {
+        plan.rice[0] = 0xFF;
+        plan.escape_bits[0] = 31;  // encode.rs:3887-3895
+    }
+    __syncthreads();
+    // exact body bits: sum over standard partitions of (u >> k)
+    unsigned long long qsum = 0;
+    if (bp >= 0) {
+        const uint32_t plen = n >> bp;
+        uint32_t i = lo > order ? lo : order;
+        if (i < hi) {
+            uint32_t cur = i / plen;
+            uint32_t bound = (cur + 1) * plen;
+            uint32_t k = S.nd_rice[(1u << bp) + cur - 1u];
+            for (; i < hi; i++) {
+                if (i == bound) {
+                    cur++;
+                    bound += plen;
+                    k = S.nd_rice[(1u << bp) + cur - 1u];
+                }
+                if (k != 0xFF) qsum += zigzag(r[i]) >> k;
+            }
+        }
+    }
+    qsum = block_sum_u64(qsum, S.red);
+    if (tid == 0) {
+        const uint32_t hb = S.method ? 5u : 4u;
+        uint32_t bits = 2u + 4u;  // coding method + partition order (encode.rs:3949, 3902)
+        if (bp >= 0) {
+            for (uint32_t q = 0; q < count; q++) {
+                uint32_t nd = (1u << bp) + first_j + q - 1u;
+                uint32_t c = S.nd_cnt[nd];
+                if (S.nd_kind[nd] == PK_STANDARD)
+                    bits += hb + (1u + S.nd_rice[nd]) * c;
+                else if (S.nd_kind[nd] == PK_ESCAPED)
+                    bits += hb + 5u + (uint32_t)S.nd_esc[nd] * c;
+                else
+                    bits += hb + 5u;
+            }
+            bits += (uint32_t)qsum;
+            plan.part_len = n >> bp;
+        } else {
+            bits += hb + 5u + 31u * (n - order);
+            plan.part_len = n;
+        }
+        plan.coding_method = (uint8_t)S.method;
+        plan.n_partitions = count;
+        plan.partition_order = (uint8_t)(31u - (uint32_t)__builtin_clz(count));
+        S.nd_est[0] = bits;
+    }
+    __syncthreads();
+    resid_bits = S.nd_est[0];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void plan_clear(SubPlan &plan) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&plan);
+    for (uint32_t i = threadIdx.x; i < sizeof(SubPlan) / 4; i += WG) w[i] = 0;
+}
+__device__ __forceinline__ void plan_store(SubPlan *dst, const SubPlan &src) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&src);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    for (uint32_t i = threadIdx.x; i < sizeof(SubPlan) / 4; i += WG) d[i] = s[i];
+}
+
+// fixed / LPC / verbatim choice of encode_subframe (encode.rs:2929-2979), thread 0 only.
+// returns 0: keep `best`, 1: VERBATIM
+__device__ __forceinline__ void make_verbatim(SubPlan &plan, uint32_t n, uint32_t bps_eff,
+                                              uint32_t wasted, uint8_t source) {
+    plan.type = FLACGPU_SUB_VERBATIM;
+    plan.wasted = (uint8_t)wasted;
+    plan.bps = (uint8_t)bps_eff;
+    plan.order = 0;
+    plan.precision = 0;
+    plan.shift = 0;
+    plan.coding_method = 0;
+    plan.partition_order = 0;
+    plan.source = source;
+    plan.n_partitions = 0;
+    plan.part_len = 0;
+    plan.bits = 8u + wasted + n * bps_eff;
+}
+
+// ---------------------------------------------------------------------------------
+// K0: de-interleave (audio.rs:190-199)  [pcm_frame][ch] -> [flac_frame][ch][ldb]
+// also used to re-stride planar input whose block size is not a multiple of 4
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_deinterleave(const int32_t *__restrict__ in,
+                                                     int32_t *__restrict__ out, uint32_t channels,
+                                                     uint32_t block_size, uint32_t ldb,
+                                                     uint32_t n_frames, uint32_t last_len,
+                                                     int planar_in) {
+    const uint32_t frame = blockIdx.y;
+    const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
+    const size_t in_base = (size_t)frame * block_size * channels;
+    int32_t *o = out + (size_t)frame * channels * ldb;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        for (uint32_t c = 0; c < channels; c++) {
+            int32_t v = planar_in ? in[in_base + (size_t)c * n + i]
+                                  : in[in_base + (size_t)i * channels + c];
+            o[(size_t)c * ldb + i] = v;
+        }
+    }
+}
+
+// stereo fast path: both channels of an interleaved pair in one 8-byte load
+__global__ void __launch_bounds__(WG) k_deinterleave2(const int2 *__restrict__ in,
+                                                      int32_t *__restrict__ out,
+                                                      uint32_t block_size, uint32_t ldb,
+                                                      uint32_t n_frames, uint32_t last_len) {
+    const uint32_t frame = blockIdx.y;
+    const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
+    const int2 *src = in + (size_t)frame * block_size;
+    int32_t *o = out + (size_t)frame * 2 * ldb;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        int2 v = src[i];
+        o[i] = v.x;
+        o[ldb + i] = v.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K1: correlate_channels (fast, non-exhaustive), encode.rs:2463-2674
+// one workgroup per frame: abs sums of L, R, M, S -> assignment + active candidates
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_stereo_stats(Params p) {
+    __shared__ uint64_t red[4];
+    const uint32_t frame = blockIdx.x;
+    const uint32_t n = frame_len(p, frame);
+    const int32_t *L = p.planar + (size_t)frame * 2 * p.ldb;
+    const int32_t *R = L + p.ldb;
+    uint64_t ls = 0, rs = 0, ms = 0, ss = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += WG) {
+        int32_t l = L[i], r = R[i];
+        ls += uabs(l);
+        rs += uabs(r);
+        ms += uabs(combine(1, l, r));
+        ss += uabs(combine(2, l, r));
+    }
+    ls = block_sum_u64(ls, red);
+    rs = block_sum_u64(rs, red);
+    ms = block_sum_u64(ms, red);
+    ss = block_sum_u64(ss, red);
+    if (threadIdx.x == 0) {
+        uint8_t assign;
+        if (p.mid_side) {  // candidate order :2506-2514
+            uint64_t tot[4] = {ls + rs, ls + ss, ss + rs, ms + ss};
+            int b = 0;
+            for (int i = 1; i < 4; i++)
+                if (tot[i] < tot[b]) b = i;
+            assign = b == 0 ? FLACGPU_ASSIGN_INDEPENDENT
+                   : b == 1 ? FLACGPU_ASSIGN_LEFT_SIDE
+                   : b == 2 ? FLACGPU_ASSIGN_SIDE_RIGHT : FLACGPU_ASSIGN_MID_SIDE;
+        } else {  // candidate order :2600-2607: LeftSide, SideRight, Independent
+            uint64_t tot[3] = {ls + ss, ss + rs, ls + rs};
+            int b = 0;
+            for (int i = 1; i < 3; i++)
+                if (tot[i] < tot[b]) b = i;
+            assign = b == 0 ? FLACGPU_ASSIGN_LEFT_SIDE
+                   : b == 1 ? FLACGPU_ASSIGN_SIDE_RIGHT : FLACGPU_ASSIGN_INDEPENDENT;
+        }
+        p.finfo[frame].assignment = assign;
+        CandInfo *ci = p.cinfo + (size_t)frame * p.ncand;
+        ci[0].active = (assign == FLACGPU_ASSIGN_INDEPENDENT || assign == FLACGPU_ASSIGN_LEFT_SIDE);
+        ci[1].active = (assign == FLACGPU_ASSIGN_INDEPENDENT || assign == FLACGPU_ASSIGN_SIDE_RIGHT);
+        ci[2].active = (assign == FLACGPU_ASSIGN_MID_SIDE);
+        ci[3].active = (assign != FLACGPU_ASSIGN_INDEPENDENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K2: wasted bits + FIXED predictor analysis, one workgroup per (frame, candidate)
+// dynamic LDS: x[n] | r[n]
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_fixed(Params p) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ RiceShared RS;
+    __shared__ SubPlan plan;
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t sums[5];
+
+    uint32_t frame, cand;
+    map_block(blockIdx.x, p.ncand, p.n_frames, frame, cand);
+    const uint32_t n = frame_len(p, frame);
+    const size_t cidx = (size_t)frame * p.ncand + cand;
+    const uint32_t tid = threadIdx.x;
+    CandInfo *ci = p.cinfo + cidx;
+    if (p.exhaustive || !p.stereo4) {
+        // exhaustive: L, R always; S if bps+1 <= 32 (guaranteed by stereo4); M iff mid_side
+        if (p.stereo4 && cand == 2 && !p.mid_side) {
+            if (tid == 0) ci->active = 0;
+            return;
+        }
+        if (tid == 0) ci->active = 1;
+    } else if (!ci->active) {
+        return;  // k_stereo_stats deselected this candidate
+    }
+    int32_t *x = lds;
+    int32_t *r = lds + p.block_size;
+    const CandSrc src = cand_src(p, frame, cand);
+
+    uint32_t orv = 0;
+    for (uint32_t i = tid; i < n; i += WG) {
+        int32_t v = combine(src.mode, src.a[i], src.b[i]);
+        x[i] = v;
+        orv |= (uint32_t)v;
+    }
+    orv = block_or_u32(orv, red);
+    plan_clear(plan);
+    __syncthreads();
+    // encode.rs:2878-2898: min trailing zeros over all samples (zero counts as 32)
+    const uint32_t wasted = orv ? (uint32_t)__builtin_ctz(orv) : 32u;
+    if (wasted == 32u) {  // all zero -> CONSTANT(0) at the candidate's bps, wasted 0 (:2883-2887)
+        if (tid == 0) {
+            plan.type = FLACGPU_SUB_CONSTANT;
+            plan.bps = (uint8_t)src.bps;
+            plan.source = src.source;
+            plan.bits = 8u + src.bps;
+            ci->wasted = 0;
+            ci->bps = (uint8_t)src.bps;
+            ci->is_const = 1;
+        }
+        __syncthreads();
+        plan_store(p.fixed_plan + cidx, plan);
+        plan_store(p.cand_plan + cidx, plan);
+        return;
+    }
+    const uint32_t bps_eff = src.bps - wasted;
+    if (wasted)
+        for (uint32_t i = tid; i < n; i += WG) x[i] >>= wasted;
+    __syncthreads();
+
+    // available orders, encode.rs:3039-3060
+    uint32_t maxo = n - 1 < 4u ? n - 1 : 4u;
+    if (bps_eff >= 28 && maxo > 0) {  // first differences can overflow i32 only then
+        uint32_t ovf = 0;
+        for (uint32_t i = tid; i < n; i += WG) {
+            long long x0 = x[i];
+            if (i >= 1) {
+                long long d1 = x0 - x[i - 1];
+                if (d1 < INT32_MIN || d1 > INT32_MAX) ovf |= 1u;
+                if (i >= 2) {
+                    long long d2 = x0 - 2ll * x[i - 1] + x[i - 2];
+                    if (d2 < INT32_MIN || d2 > INT32_MAX) ovf |= 2u;
+                    if (i >= 3) {
+                        long long d3 = x0 - 3ll * x[i - 1] + 3ll * x[i - 2] - x[i - 3];
+                        if (d3 < INT32_MIN || d3 > INT32_MAX) ovf |= 4u;
+                        if (i >= 4) {
+                            long long d4 = x0 - 4ll * x[i - 1] + 6ll * x[i - 2] - 4ll * x[i - 3] +
+                                           x[i - 4];
+                            if (d4 < INT32_MIN || d4 > INT32_MAX) ovf |= 8u;
+                        }
+                    }
+                }
+            }
+        }
+        ovf = block_or_u32(ovf, red);
+        for (uint32_t k = 1; k <= maxo; k++)
+            if (ovf & (1u << (k - 1))) {
+                maxo = k - 1;
+                break;
+            }
+    }
+    // abs sums over the common tail [maxo, n), encode.rs:3062-3073
+    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    for (uint32_t i = maxo + tid; i < n; i += WG) {
+        long long x0 = x[i];
+        s0 += uabs((int32_t)x0);
+        if (maxo >= 1) {
+            long long xm1 = x[i - 1];
+            s1 += uabs((int32_t)(x0 - xm1));
+            if (maxo >= 2) {
+                long long xm2 = x[i - 2];
+                s2 += uabs((int32_t)(x0 - 2 * xm1 + xm2));
+                if (maxo >= 3) {
+                    long long xm3 = x[i - 3];
+                    s3 += uabs((int32_t)(x0 - 3 * xm1 + 3 * xm2 - xm3));
+                    if (maxo >= 4) {
+                        long long xm4 = x[i - 4];
+                        s4 += uabs((int32_t)(x0 - 4 * xm1 + 6 * xm2 - 4 * xm3 + xm4));
+                    }
+                }
+            }
+        }
+    }
+    s0 = block_sum_u64(s0, red);
+    s1 = block_sum_u64(s1, red);
+    s2 = block_sum_u64(s2, red);
+    s3 = block_sum_u64(s3, red);
+    s4 = block_sum_u64(s4, red);
+    if (tid == 0) {
+        sums[0] = s0; sums[1] = s1; sums[2] = s2; sums[3] = s3; sums[4] = s4;
+    }
+    __syncthreads();
+    uint32_t order = 0;
+    for (uint32_t k = 1; k <= maxo; k++)
+        if (sums[k] < sums[order]) order = k;  // min_by_key: first minimum wins
+    // residuals of the chosen order, indexed by sample position
+    for (uint32_t i = order + tid; i < n; i += WG) {
+        long long v = x[i];
+        if (order == 1) v = v - x[i - 1];
+        else if (order == 2) v = v - 2ll * x[i - 1] + x[i - 2];
+        else if (order == 3) v = v - 3ll * x[i - 1] + 3ll * x[i - 2] - x[i - 3];
+        else if (order == 4) v = v - 4ll * x[i - 1] + 6ll * x[i - 2] - 4ll * x[i - 3] + x[i - 4];
+        r[i] = (int32_t)v;
+    }
+    __syncthreads();
+    uint32_t rbits;
+    rice_search(r, n, order, p, RS, plan, rbits);
+    if (tid == 0) {
+        plan.type = FLACGPU_SUB_FIXED;
+        plan.wasted = (uint8_t)wasted;
+        plan.bps = (uint8_t)bps_eff;
+        plan.order = (uint8_t)order;
+        plan.source = src.source;
+        plan.bits = 8u + wasted + order * bps_eff + rbits;
+        ci->wasted = (uint8_t)wasted;
+        ci->bps = (uint8_t)bps_eff;
+        ci->is_const = 0;
+    }
+    __syncthreads();
+    plan_store(p.fixed_plan + cidx, plan);
+    if (p.max_lpc_order == 0) {  // no LPC candidate: final choice here (encode.rs:2947-2979)
+        __syncthreads();
+        const bool verbatim = !(plan.bits < n * bps_eff);
+        __syncthreads();
+        if (verbatim) plan_clear(plan);
+        __syncthreads();
+        if (tid == 0 && verbatim) make_verbatim(plan, n, bps_eff, wasted, src.source);
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K3: window + autocorrelation in the reference's exact summation order.
+// ac[lag] = sum_{i=0}^{n-1-lag} w[i]*w[i+lag] is a LEFT FOLD with every product rounded
+// first (encode.rs:3495).  Equivalently, for j = lag..n-1: acc[lag] += w[j]*w[j-lag] in
+// increasing j -- the same products in the same order.  One lane owns one candidate and a
+// group of LG lags; it walks its candidate's samples sequentially, keeps the last H
+// windowed samples in a statically indexed register ring and updates its LG chains
+// (independent => full f64 pipeline with one wave per SIMD).  blockIdx.y selects the lag
+// group so the ring indexing stays static.  The window value is wave-uniform (scalar load).
+// H lags are computed (H = max order + 1 rounded up to a multiple of 4); extra lags are
+// simply not read by k_lpc.
+// ---------------------------------------------------------------------------------
+constexpr int AC_LD = 36;  // row stride of the ac buffer (max H)
+
+template <int H, int A, int LG, bool FIRST, bool GUARDED>
+__device__ __forceinline__ void ac_block(double (&hist)[H], double (&acc)[LG], const int32_t *pa,
+                                         const int32_t *pb, int mode, uint32_t wasted,
+                                         const double *__restrict__ win, uint32_t base, uint32_t n) {
+    int32_t xa[H], xb[H];
+    if (GUARDED) {  // first / last block: element loads that never touch memory past the row
+#pragma unroll
+        for (int s = 0; s < H; s++) {
+            const bool in = base + s < n;
+            xa[s] = in ? pa[base + s] : 0;
+            xb[s] = in ? pb[base + s] : 0;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < H / 4; q++) {
+            const int4 va = *reinterpret_cast<const int4 *>(pa + base + 4 * q);
+            const int4 vb = *reinterpret_cast<const int4 *>(pb + base + 4 * q);
+            xa[4 * q] = va.x; xa[4 * q + 1] = va.y; xa[4 * q + 2] = va.z; xa[4 * q + 3] = va.w;
+            xb[4 * q] = vb.x; xb[4 * q + 1] = vb.y; xb[4 * q + 2] = vb.z; xb[4 * q + 3] = vb.w;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < H; s++) {
+        const int32_t v = combine(mode, xa[s], xb[s]) >> wasted;
+        const double w = (double)v * win[base + s];  // Window::apply, encode.rs:1799
+        hist[s] = w;
+        if (!GUARDED || base + s < n) {
+#pragma unroll
+            for (int k = 0; k < LG; k++) {
+                const int lag = A + k;
+                if (!FIRST || s >= lag) {
+                    const double prod = w * hist[(s - lag + 2 * H) % H];
+                    acc[k] = acc[k] + prod;
+                }
+            }
+        }
+    }
+}
+
+template <int H, int A, int LG>
+__device__ __forceinline__ void ac_body(const Params &p, uint32_t frame0, uint32_t nframes,
+                                        uint32_t n, const double *__restrict__ win) {
+    const uint32_t lane_cand = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t total = nframes * p.ncand;
+    const bool live = lane_cand < total;
+    const uint32_t cc = live ? lane_cand : 0;
+    const uint32_t frame = frame0 + cc / p.ncand;
+    const uint32_t cand = cc % p.ncand;
+    const CandSrc src = cand_src(p, frame, cand);
+    const CandInfo ci = p.cinfo[(size_t)frame * p.ncand + cand];
+    const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
+
+    double hist[H], acc[LG];
+#pragma unroll
+    for (int k = 0; k < LG; k++) acc[k] = -0.0;  // f64 `sum()` identity
+#pragma unroll
+    for (int s = 0; s < H; s++) hist[s] = 0.0;
+
+    ac_block<H, A, LG, true, true>(hist, acc, src.a, src.b, src.mode, wasted, win, 0, n);
+    uint32_t base = H;
+    for (; base + H <= n; base += H)
+        ac_block<H, A, LG, false, false>(hist, acc, src.a, src.b, src.mode, wasted, win, base, n);
+    if (base < n)
+        ac_block<H, A, LG, false, true>(hist, acc, src.a, src.b, src.mode, wasted, win, base, n);
+
+    if (live) {
+        double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
+#pragma unroll
+        for (int k = 0; k < LG; k++) out[k] = acc[k];
+    }
+}
+
+// G = 4 lag groups per candidate (blockIdx.y)
+template <int H>
+__global__ void __launch_bounds__(64) k_autocorr(Params p, uint32_t frame0, uint32_t nframes,
+                                                 uint32_t n, const double *__restrict__ win) {
+    constexpr int LG = H / 4;
+    switch (blockIdx.y) {
+    case 0: ac_body<H, 0 * LG, LG>(p, frame0, nframes, n, win); break;
+    case 1: ac_body<H, 1 * LG, LG>(p, frame0, nframes, n, win); break;
+    case 2: ac_body<H, 2 * LG, LG>(p, frame0, nframes, n, win); break;
+    default: ac_body<H, 3 * LG, LG>(p, frame0, nframes, n, win); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K4: Levinson-Durbin + order estimate + quantisation, one lane per candidate
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ long long total_key(double x) {  // f64::total_cmp key
+    long long b = __double_as_longlong(x);
+    b ^= (long long)((unsigned long long)(b >> 63) >> 1);
+    return b;
+}
+
+__global__ void __launch_bounds__(64) k_lpc(Params p) {
+    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= p.n_frames * p.ncand) return;
+    const uint32_t frame = idx / p.ncand;
+    const uint32_t n = frame_len(p, frame);
+    const CandInfo ci = p.cinfo[idx];
+    LpcParams *out = p.lpc + idx;
+    if (!ci.active || ci.is_const) {
+        out->status = 1;
+        return;
+    }
+    const uint32_t L = p.max_lpc_order;
+    if (n <= L) {  // InsufficientLpcSamples, encode.rs:3300
+        out->status = 1;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    // precision table, encode.rs:3305-3315
+    const uint32_t precision = n <= 192 ? 7 : n <= 384 ? 8 : n <= 576 ? 9 : n <= 1152 ? 10
+                               : n <= 2304 ? 11 : n <= 4608 ? 12 : 13;
+    const double *ac = p.ac + (size_t)idx * AC_LD;
+    double c[FLACGPU_MAX_LPC_ORDER], cn[FLACGPU_MAX_LPC_ORDER], errs[FLACGPU_MAX_LPC_ORDER];
+    // pass 1: errors of every order (lp_coefficients, encode.rs:3536-3580)
+    {
+        double k = ac[1] / ac[0];
+        c[0] = k;
+        double err = ac[0] * (1.0 - k * k);
+        errs[0] = err;
+        for (uint32_t i = 1; i < L; i++) {
+            double s = -0.0;
+            for (uint32_t j = 0; j < i; j++) {
+                double prod = ac[i - j] * c[j];
+                s = s + prod;
+            }
+            double q = ac[i + 1] - s;
+            double kk = q / err;
+            for (uint32_t j = 0; j < i; j++) {
+                double t = kk * c[i - 1 - j];
+                cn[j] = c[j] - t;
+            }
+            cn[i] = kk;
+            for (uint32_t j = 0; j <= i; j++) c[j] = cn[j];
+            err = err * (1.0 - kk * kk);
+            errs[i] = err;
+        }
+    }
+    // compute_best_order, encode.rs:3656-3702 (bits-per-residual NOT clamped, :3675)
+    const double LN_2 = 0.693147180559945309417232121458176568;
+    const double error_scale = 0.5 / (double)n;
+    const double denom = 2.0 * LN_2;
+    int best = -1;
+    double best_bits = 0.0, second = 0.0;
+    bool have_second = false;
+    for (uint32_t i = 0; i < L; i++) {
+        if (!(errs[i] > 0.0)) break;  // take_while(error > 0.0)
+        uint32_t order = i + 1;
+        double header_bits = (double)(order * ((uint32_t)ci.bps + precision));
+        double bpr = log(errs[i] * error_scale) / denom;
+        double bits = __builtin_fma(bpr, (double)(n - order), header_bits);
+        if (best < 0) {
+            best = (int)i;
+            best_bits = bits;
+        } else if (total_key(bits) < total_key(best_bits)) {
+            second = best_bits;
+            have_second = true;
+            best = (int)i;
+            best_bits = bits;
+        } else if (!have_second || total_key(bits) < total_key(second)) {
+            second = bits;
+            have_second = true;
+        }
+    }
+    if (best < 0) {  // NoBestLpcOrder
+        out->status = 2;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    if (have_second && fabs(second - best_bits) <= 1e-9 * fabs(best_bits)) atomicAdd(&p.stats[1], 1u);
+    const uint32_t order = (uint32_t)best + 1;
+    // pass 2: coefficients of the chosen order (same recursion, same roundings)
+    {
+        double k = ac[1] / ac[0];
+        c[0] = k;
+        double err = ac[0] * (1.0 - k * k);
+        for (uint32_t i = 1; i < order; i++) {
+            double s = -0.0;
+            for (uint32_t j = 0; j < i; j++) {
+                double prod = ac[i - j] * c[j];
+                s = s + prod;
+            }
+            double q = ac[i + 1] - s;
+            double kk = q / err;
+            for (uint32_t j = 0; j < i; j++) {
+                double t = kk * c[i - 1 - j];
+                cn[j] = c[j] - t;
+            }
+            cn[i] = kk;
+            for (uint32_t j = 0; j <= i; j++) c[j] = cn[j];
+            err = err * (1.0 - kk * kk);
+        }
+    }
+    // quantize, encode.rs:3334-3401
+    const int32_t max_coeff = (1 << (precision - 1)) - 1, min_coeff = -(1 << (precision - 1));
+    double l = fabs(c[0]);
+    for (uint32_t i = 1; i < order; i++) {
+        double a = fabs(c[i]);
+        if (total_key(a) >= total_key(l)) l = a;
+    }
+    if (!(l > 0.0)) {  // ZeroLpCoefficients (also NaN)
+        out->status = 3;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    // floor(log2(l)) as the host libm computes it: exponent, bumped when l sits in the
+    // (few-ulp) band below 2^(e+1) where log2() rounds up to e+1 (table built on the host)
+    int32_t fl;
+    if (isinf(l)) {
+        fl = INT32_MAX;
+    } else {
+        int e = ilogb(l);
+        fl = e;
+        if (e >= -64 && e < 64 && l >= p.log2_thr[e + 64]) {
+            fl = e + 1;
+            atomicAdd(&p.stats[2], 1u);
+        }
+    }
+    int32_t sh = (int32_t)((uint32_t)(int32_t)(precision - 1) - (uint32_t)fl - 1u);
+    if (sh > 15) sh = 15;
+    if (sh < -16) {  // LpNegativeShiftError
+        out->status = 4;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    double error = 0.0;
+    const double scale = (double)(1 << (sh >= 0 ? sh : -sh));
+    for (uint32_t i = 0; i < order; i++) {
+        double sum = sh >= 0 ? __builtin_fma(c[i], scale, error) : (c[i] / scale) + error;
+        double rr = round(sum);
+        int32_t q = (rr != rr) ? 0 : rr >= 2147483647.0 ? INT32_MAX : rr <= -2147483648.0 ? INT32_MIN
+                                                                                         : (int32_t)rr;
+        q = q < min_coeff ? min_coeff : q > max_coeff ? max_coeff : q;
+        error = sum - (double)q;
+        out->qlp[i] = q;
+    }
+    out->status = 0;
+    out->order = (uint8_t)order;
+    out->precision = (uint8_t)precision;
+    out->shift = (uint8_t)(sh >= 0 ? sh : 0);
+}
+
+// ---------------------------------------------------------------------------------
+// K5: LPC FIR residual + Rice search + fixed/LPC/verbatim choice, one workgroup per
+// (frame, candidate).  dynamic LDS: x[n] | r[n]
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_fir(Params p) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ RiceShared RS;
+    __shared__ SubPlan plan;
+    __shared__ uint64_t red[4];
+    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+
+    uint32_t frame, cand;
+    map_block(blockIdx.x, p.ncand, p.n_frames, frame, cand);
+    const uint32_t n = frame_len(p, frame);
+    const size_t cidx = (size_t)frame * p.ncand + cand;
+    const uint32_t tid = threadIdx.x;
+    const CandInfo ci = p.cinfo[cidx];
+    if (!ci.active || ci.is_const) return;  // CONSTANT already final (k_fixed)
+    const LpcParams *lp = p.lpc + cidx;
+    const CandSrc src = cand_src(p, frame, cand);
+    const uint32_t wasted = ci.wasted, bps_eff = ci.bps;
+    const int32_t status = lp->status;
+    bool lpc_ok = status == 0;
+    uint32_t lpc_bits = 0;
+    plan_clear(plan);
+    if (lpc_ok) {
+        int32_t *x = lds;
+        int32_t *r = lds + p.block_size;
+        const uint32_t order = lp->order, shift = lp->shift;
+        if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = tid < order ? lp->qlp[tid] : 0;
+        for (uint32_t i = tid; i < n; i += WG) x[i] = combine(src.mode, src.a[i], src.b[i]) >> wasted;
+        __syncthreads();
+        // encode_residuals, encode.rs:3181-3197
+        uint32_t ovf = 0;
+        for (uint32_t i = order + tid; i < n; i += WG) {
+            long long sum = 0;
+            for (uint32_t j = 0; j < order; j++) sum += (long long)x[i - 1 - j] * (long long)qlp[j];
+            int32_t pred = (int32_t)(sum >> shift);
+            long long d = (long long)x[i] - (long long)pred;
+            if (d < INT32_MIN || d > INT32_MAX) ovf = 1;  // checked_sub -> ResidualOverflow
+            r[i] = (int32_t)d;
+        }
+        ovf = block_or_u32(ovf, red);
+        if (ovf) {
+            lpc_ok = false;
+            if (tid == 0) atomicAdd(&p.stats[0], 1u);
+        } else {
+            uint32_t rbits;
+            rice_search(r, n, order, p, RS, plan, rbits);
+            lpc_bits = 8u + wasted + order * bps_eff + 4u + 5u + order * lp->precision + rbits;
+        }
+    }
+    __syncthreads();
+    const SubPlan *fx = p.fixed_plan + cidx;
+    const uint32_t fixed_bits = fx->bits;
+    // (Ok,Ok) -> min_by_key(written) with FIXED first: tie keeps FIXED (encode.rs:2929-2934)
+    const bool use_lpc = lpc_ok && lpc_bits < fixed_bits;
+    const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
+    const bool verbatim = !(best_bits < n * bps_eff);  // encode.rs:2971-2979
+    if (verbatim) {
+        __syncthreads();
+        plan_clear(plan);
+        __syncthreads();
+        if (tid == 0) make_verbatim(plan, n, bps_eff, wasted, src.source);
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    } else if (use_lpc) {
+        if (tid == 0) {
+            plan.type = FLACGPU_SUB_LPC;
+            plan.wasted = (uint8_t)wasted;
+            plan.bps = (uint8_t)bps_eff;
+            plan.order = lp->order;
+            plan.precision = lp->precision;
+            plan.shift = lp->shift;
+            plan.source = src.source;
+            plan.bits = lpc_bits;
+        }
+        if (tid < FLACGPU_MAX_LPC_ORDER) plan.coeffs[tid] = qlp[tid];
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    } else {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(fx);
+        uint32_t *d = reinterpret_cast<uint32_t *>(p.cand_plan + cidx);
+        for (uint32_t i = tid; i < sizeof(SubPlan) / 4; i += WG) d[i] = s[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K6: channel-assignment choice, one wave per frame (lane 0 decides, the wave copies)
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_decide(Params p) {
+    const uint32_t frame = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = frame_len(p, frame);
+    const SubPlan *cp = p.cand_plan + (size_t)frame * p.ncand;
+    SubPlan *op = p.out_plan + (size_t)frame * p.channels;
+    uint32_t sel[FLACGPU_MAX_CHANNELS];
+    uint8_t assign = FLACGPU_ASSIGN_INDEPENDENT;
+    if (p.stereo4) {
+        if (p.exhaustive) {
+            const uint32_t l = cp[0].bits, r = cp[1].bits, s = cp[3].bits;
+            int b = 0;
+            if (p.mid_side) {  // encode.rs:2747-2768
+                const uint32_t m = cp[2].bits;
+                uint32_t tot[4] = {l + r, l + s, s + r, m + s};
+                for (int i = 1; i < 4; i++)
+                    if (tot[i] < tot[b]) b = i;
+            } else {  // encode.rs:2803-2820
+                uint32_t tot[3] = {l + r, l + s, s + r};
+                for (int i = 1; i < 3; i++)
+                    if (tot[i] < tot[b]) b = i;
+            }
+            assign = b == 0 ? FLACGPU_ASSIGN_INDEPENDENT
+                   : b == 1 ? FLACGPU_ASSIGN_LEFT_SIDE
+                   : b == 2 ? FLACGPU_ASSIGN_SIDE_RIGHT : FLACGPU_ASSIGN_MID_SIDE;
+        } else {
+            assign = p.finfo[frame].assignment;
+        }
+        switch (assign) {
+        case FLACGPU_ASSIGN_LEFT_SIDE: sel[0] = 0; sel[1] = 3; break;
+        case FLACGPU_ASSIGN_SIDE_RIGHT: sel[0] = 3; sel[1] = 1; break;
+        case FLACGPU_ASSIGN_MID_SIDE: sel[0] = 2; sel[1] = 3; break;
+        default: sel[0] = 0; sel[1] = 1; break;
+        }
+    } else {
+        for (uint32_t c = 0; c < p.channels; c++) sel[c] = c;
+    }
+    uint32_t body = 0;
+    for (uint32_t c = 0; c < p.channels; c++) {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(cp + sel[c]);
+        uint32_t *d = reinterpret_cast<uint32_t *>(op + c);
+        for (uint32_t i = lane; i < sizeof(SubPlan) / 4; i += 64) d[i] = s[i];
+        body += cp[sel[c]].bits;
+    }
+    if (lane == 0) {
+        flacgpu_frame_plan fp;
+        fp.assignment = assign;
+        fp.channels = (uint8_t)p.channels;
+        fp.block_size = (uint16_t)n;
+        fp.body_bits = body;
+        p.frame_plan[frame] = fp;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K7: residual signal of the chosen subframes, one workgroup per (frame, output channel).
+// Out row: `order` warm-up samples then the residuals (VERBATIM: the samples; CONSTANT: [0]).
+// dynamic LDS: x[n]
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_emit(Params p) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+    uint32_t frame, ch;
+    map_block(blockIdx.x, p.channels, p.n_frames, frame, ch);
+    const uint32_t n = frame_len(p, frame);
+    const uint32_t tid = threadIdx.x;
+    const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
+    const uint32_t type = sp->type, order = sp->order, wasted = sp->wasted, shift = sp->shift;
+    const uint32_t source = sp->source;
+    uint32_t cand = source;
+    if (p.stereo4) cand = source == FLACGPU_SRC_MID ? 2u : source == FLACGPU_SRC_SIDE ? 3u : source;
+    const CandSrc src = cand_src(p, frame, cand);
+    int32_t *out = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
+    int32_t *x = lds;
+    if (type == FLACGPU_SUB_LPC && tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = sp->coeffs[tid];
+    for (uint32_t i = tid; i < n; i += WG) x[i] = combine(src.mode, src.a[i], src.b[i]) >> wasted;
+    __syncthreads();
+    if (type == FLACGPU_SUB_LPC) {
+        for (uint32_t i = tid; i < n; i += WG) {
+            int32_t v = x[i];
+            if (i >= order) {
+                long long sum = 0;
+                for (uint32_t j = 0; j < order; j++) sum += (long long)x[i - 1 - j] * (long long)qlp[j];
+                v = (int32_t)((long long)v - (long long)(int32_t)(sum >> shift));
+            }
+            out[i] = v;
+        }
+    } else if (type == FLACGPU_SUB_FIXED) {
+        for (uint32_t i = tid; i < n; i += WG) {
+            long long v = x[i];
+            if (i >= order) {
+                if (order == 1) v = v - x[i - 1];
+                else if (order == 2) v = v - 2ll * x[i - 1] + x[i - 2];
+                else if (order == 3) v = v - 3ll * x[i - 1] + 3ll * x[i - 2] - x[i - 3];
+                else if (order == 4) v = v - 4ll * x[i - 1] + 6ll * x[i - 2] - 4ll * x[i - 3] + x[i - 4];
+            }
+            out[i] = (int32_t)v;
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += WG) out[i] = x[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+const char *const kKernelNames[FLACGPU_N_KERNELS] = {
+    "k_deinterleave", "k_stereo_stats", "k_fixed", "k_autocorr", "k_lpc",
+    "k_fir",          "k_decide",       "k_emit",  "(unused)",   "(unused)"};
+
+}  // namespace
+
+struct flacgpu_ctx {
+    flacgpu_options opts;
+    uint32_t bps, channels, max_frames, ldb, ncand, stereo4;
+    int device;
+    // device buffers
+    int32_t *d_in = nullptr, *d_planar = nullptr, *d_resid = nullptr;
+    double *d_window_full = nullptr, *d_window_last = nullptr, *d_log2_thr = nullptr, *d_ac = nullptr;
+    CandInfo *d_cinfo = nullptr;
+    SubPlan *d_fixed = nullptr, *d_cand = nullptr, *d_out = nullptr;
+    LpcParams *d_lpc = nullptr;
+    FrameInfo *d_finfo = nullptr;
+    flacgpu_frame_plan *d_fplan = nullptr;
+    uint32_t *d_stats = nullptr;
+    uint32_t window_last_len = 0;
+    hipStream_t own_stream = nullptr;
+    // last call
+    uint32_t last_frames = 0, last_len = 0;
+    bool timing = false;
+    hipEvent_t ev[FLACGPU_N_KERNELS + 1];
+    bool ev_ok = false;
+    bool ev_used[FLACGPU_N_KERNELS];
+    float last_ms[FLACGPU_N_KERNELS];
+};
+
+namespace {
+
+// Window::generate (encode.rs:1725-1783) on the host: it needs cos(), whose last-ulp
+// behaviour differs between libms; the table is built once per block length with the
+// host libm (the one a Rust build on this box links) and uploaded.
+void window_generate(int kind, float p, uint32_t n, std::vector<double> &w) {
+    const double PI = 3.14159265358979323846264338327950288;
+    w.assign(n, 1.0);
+    if (kind == FLACGPU_WINDOW_RECTANGLE) return;
+    auto hann = [&]() {
+        double np = (double)(uint16_t)n - 1.0;
+        for (uint32_t i = 0; i < n; i++) w[i] = 0.5 - 0.5 * cos(2.0 * PI * (double)i / np);
+    };
+    if (kind == FLACGPU_WINDOW_HANN) {
+        hann();
+        return;
+    }
+    if (p != p) p = 0.5f;  // NaN => Tukey(0.5)
+    if (p <= 0.0f) return;
+    if (p >= 1.0f) {
+        hann();
+        return;
+    }
+    double t = (double)p / 2.0 * (double)n;
+    uint64_t tu = (uint64_t)t;
+    if (tu == 0) return;
+    uint64_t np = tu - 1;
+    if (np > n || n - np < np) return;
+    double npf = (double)(uint16_t)np;
+    for (uint32_t i = 0; i < (uint32_t)np; i++) {
+        double x = 0.5 - 0.5 * cos(PI * (double)i / npf);
+        w[i] = x;
+        w[n - 1 - i] = x;
+    }
+}
+
+// thresholds for floor(log2(l)) (encode.rs:3360): for exponent e, the smallest double in
+// [2^e, 2^(e+1)) whose host log2() already rounds up to e+1 (or 2^(e+1) if none)
+void build_log2_thresholds(double *thr) {
+    for (int e = -64; e < 64; e++) {
+        double hi = ldexp(1.0, e + 1);
+        double top = nextafter(hi, 0.0);
+        if (floor(log2(top)) == (double)e) {
+            thr[e + 64] = hi;
+            continue;
+        }
+        uint64_t lo_b, hi_b;
+        double lo = ldexp(1.0, e);
+        memcpy(&lo_b, &lo, 8);
+        memcpy(&hi_b, &top, 8);
+        while (lo_b < hi_b) {  // first bit pattern with floor(log2) == e+1
+            uint64_t mid = lo_b + (hi_b - lo_b) / 2;
+            double m;
+            memcpy(&m, &mid, 8);
+            if (floor(log2(m)) == (double)e) lo_b = mid + 1;
+            else hi_b = mid;
+        }
+        memcpy(&thr[e + 64], &lo_b, 8);
+    }
+}
+
+int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
+    std::vector<double> w;
+    window_generate(c->opts.window_kind, c->opts.window_param, n, w);
+    w.resize((size_t)n + 64, 0.0);
+    HIP_TRY(hipMemcpyAsync(dst, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `w` is a local
+    return 0;
+}
+
+template <int H>
+void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                     const double *win, hipStream_t st) {
+    uint32_t lanes = nframes * p.ncand;
+    dim3 grid((lanes + 63) / 64, 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr<H>), grid, dim3(64), 0, st, p, frame0, nframes, n,
+                       win);
+}
+
+void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                       const double *win, hipStream_t st) {
+    switch (H) {
+    case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
+    case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;
+    case 12: launch_autocorr<12>(p, frame0, nframes, n, win, st); break;
+    case 16: launch_autocorr<16>(p, frame0, nframes, n, win, st); break;
+    case 20: launch_autocorr<20>(p, frame0, nframes, n, win, st); break;
+    case 24: launch_autocorr<24>(p, frame0, nframes, n, win, st); break;
+    case 28: launch_autocorr<28>(p, frame0, nframes, n, win, st); break;
+    case 32: launch_autocorr<32>(p, frame0, nframes, n, win, st); break;
+    default: launch_autocorr<36>(p, frame0, nframes, n, win, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *flacgpu_last_error(void) { return g_last_error.c_str(); }
+const char *flacgpu_kernel_name(int i) {
+    return (i >= 0 && i < FLACGPU_N_KERNELS) ? kKernelNames[i] : "";
+}
+
+int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, int device,
+                   uint32_t max_frames, flacgpu_ctx **out) {
+    if (!o || !out) return FLACGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    // Options validation, encode.rs:1418-1455; stream validation, :495, :1904
+    if (o->block_size < 16 || o->block_size > 65535 || o->max_lpc_order > 32 ||
+        o->max_partition_order > 15 || bps < 1 || bps > 32 || channels < 1 || channels > 8 ||
+        max_frames == 0) {
+        g_last_error = "invalid option / stream parameter";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    if (o->block_size > FLACGPU_MAX_BLOCK_SIZE) {
+        g_last_error = "block_size > FLACGPU_MAX_BLOCK_SIZE is not supported by the LDS-resident kernels";
+        return FLACGPU_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_last_error = "no HIP device";
+        return FLACGPU_ERR_NO_DEVICE;
+    }
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipGetDevice(&device));
+    flacgpu_ctx *c = new flacgpu_ctx();
+    c->opts = *o;
+    c->bps = bps;
+    c->channels = channels;
+    c->max_frames = max_frames;
+    c->device = device;
+    c->ldb = (o->block_size + 3u) & ~3u;
+    c->stereo4 = (channels == 2 && bps < 32) ? 1u : 0u;  // side needs bps+1 <= 32 (encode.rs:2715)
+    c->ncand = c->stereo4 ? 4u : channels;
+    const size_t F = max_frames, B = o->block_size, C = channels, NC = c->ncand;
+    const size_t slack = 64;
+#define ALLOC(ptr, count) HIP_TRY(hipMalloc((void **)&(ptr), sizeof(*(ptr)) * (count)))
+    ALLOC(c->d_in, F * B * C + slack);
+    ALLOC(c->d_planar, F * C * c->ldb + slack);
+    ALLOC(c->d_resid, F * C * B);
+    ALLOC(c->d_window_full, B + slack);
+    ALLOC(c->d_window_last, B + slack);
+    ALLOC(c->d_log2_thr, 128);
+    ALLOC(c->d_ac, F * NC * AC_LD);
+    ALLOC(c->d_cinfo, F * NC);
+    ALLOC(c->d_fixed, F * NC);
+    ALLOC(c->d_cand, F * NC);
+    ALLOC(c->d_out, F * C);
+    ALLOC(c->d_lpc, F * NC);
+    ALLOC(c->d_finfo, F);
+    ALLOC(c->d_fplan, F);
+    ALLOC(c->d_stats, 4);
+#undef ALLOC
+    HIP_TRY(hipStreamCreate(&c->own_stream));
+    HIP_TRY(hipMemsetAsync(c->d_planar, 0, sizeof(int32_t) * (F * C * c->ldb + slack), c->own_stream));
+    HIP_TRY(hipMemsetAsync(c->d_cinfo, 0, sizeof(CandInfo) * F * NC, c->own_stream));
+    double thr[128];
+    build_log2_thresholds(thr);
+    HIP_TRY(hipMemcpyAsync(c->d_log2_thr, thr, sizeof thr, hipMemcpyHostToDevice, c->own_stream));
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    if (int rc = upload_window(c, o->block_size, c->d_window_full, c->own_stream)) return rc;
+    // k_fixed / k_fir use 2 * block_size * 4 bytes of dynamic LDS (up to 128 KiB of the 160)
+    const int dyn = (int)(2 * B * sizeof(int32_t));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, dyn / 2));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    c->ev_ok = true;
+    *out = c;
+    return FLACGPU_OK;
+}
+
+void flacgpu_destroy(flacgpu_ctx *c) {
+    if (!c) return;
+    hipFree(c->d_in); hipFree(c->d_planar); hipFree(c->d_resid); hipFree(c->d_window_full);
+    hipFree(c->d_window_last); hipFree(c->d_log2_thr); hipFree(c->d_ac); hipFree(c->d_cinfo);
+    hipFree(c->d_fixed); hipFree(c->d_cand); hipFree(c->d_out); hipFree(c->d_lpc);
+    hipFree(c->d_finfo); hipFree(c->d_fplan); hipFree(c->d_stats);
+    if (c->ev_ok) for (auto &e : c->ev) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int flacgpu_set_timing(flacgpu_ctx *c, int enable) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    c->timing = enable != 0;
+    return 0;
+}
+
+int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                           uint32_t last_len, void *stream) {
+    if (!c || !d_pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size || (layout != 0 && layout != 1)) {
+        g_last_error = "invalid analyze arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const uint32_t B = c->opts.block_size;
+    // the reference collects partitions into ArrayVec<_, 64> and panics beyond (encode.rs:3880)
+    for (uint32_t n : {n_frames > 1 ? B : last_len, last_len}) {
+        uint32_t tz = (uint32_t)__builtin_ctz(n);
+        if ((tz < c->opts.max_partition_order ? tz : c->opts.max_partition_order) > (uint32_t)MAXP) {
+            g_last_error = "effective partition order > 6: the reference panics (MAX_PARTITIONS = 64)";
+            return FLACGPU_ERR_UNSUPPORTED;
+        }
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    if (last_len != B && last_len != c->window_last_len) {
+        if (int rc = upload_window(c, last_len, c->d_window_last, st)) return rc;
+        c->window_last_len = last_len;
+    }
+    Params p;
+    memset(&p, 0, sizeof p);
+    p.channels = c->channels;
+    p.bps = c->bps;
+    p.block_size = B;
+    p.ldb = c->ldb;
+    p.ncand = c->ncand;
+    p.stereo4 = c->stereo4;
+    p.mid_side = c->opts.mid_side;
+    p.exhaustive = c->opts.exhaustive_channel_correlation;
+    p.max_lpc_order = c->opts.max_lpc_order;
+    p.max_po = c->opts.max_partition_order;
+    p.use_rice2 = c->bps > 16;  // encode.rs:1965
+    p.n_frames = n_frames;
+    p.last_len = last_len;
+    p.planar = c->d_planar;
+    p.window_full = c->d_window_full;
+    p.window_last = c->d_window_last;
+    p.log2_thr = c->d_log2_thr;
+    p.cinfo = c->d_cinfo;
+    p.fixed_plan = c->d_fixed;
+    p.cand_plan = c->d_cand;
+    p.out_plan = c->d_out;
+    p.lpc = c->d_lpc;
+    p.ac = c->d_ac;
+    p.finfo = c->d_finfo;
+    p.frame_plan = c->d_fplan;
+    p.residuals = c->d_resid;
+    p.stats = c->d_stats;
+
+    int evi = 0;
+    for (auto &u : c->ev_used) u = false;
+    auto mark = [&](int k) {  // event BEFORE kernel k; the next mark closes it
+        if (c->timing) {
+            hipEventRecord(c->ev[evi], st);
+            c->ev_used[k] = true;
+            evi++;
+        }
+    };
+    int order_of_marks[FLACGPU_N_KERNELS];
+    int n_marks = 0;
+    auto begin = [&](int k) {
+        order_of_marks[n_marks++] = k;
+        mark(k);
+    };
+
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(uint32_t), st));
+    // K0
+    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
+    begin(0);
+    if (planar_direct) {
+        p.planar = d_pcm;  // [frame][ch][B] with ldb == B
+    } else {
+        dim3 grid((B + WG - 1) / WG, n_frames);
+        if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2)
+            hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm,
+                               c->d_planar, B, c->ldb, n_frames, last_len);
+        else
+            hipLaunchKernelGGL(k_deinterleave, grid, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels,
+                               B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR);
+    }
+    const uint32_t ncb = n_frames * c->ncand;
+    const size_t dyn2 = 2 * (size_t)B * sizeof(int32_t);
+    if (c->stereo4 && !p.exhaustive) {
+        begin(1);
+        hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
+    }
+    begin(2);
+    hipLaunchKernelGGL(k_fixed, dim3(ncb), dim3(WG), dyn2, st, p);
+    if (p.max_lpc_order > 0) {
+        const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
+        begin(3);
+        const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
+        if (full) dispatch_autocorr(H, p, 0, full, B, c->d_window_full, st);
+        if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
+        begin(4);
+        hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
+        begin(5);
+        hipLaunchKernelGGL(k_fir, dim3(ncb), dim3(WG), dyn2, st, p);
+    }
+    begin(6);
+    hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
+    begin(7);
+    hipLaunchKernelGGL(k_emit, dim3(n_frames * c->channels), dim3(WG), dyn2 / 2, st, p);
+    if (c->timing) hipEventRecord(c->ev[evi], st);
+    HIP_TRY(hipGetLastError());
+    c->last_frames = n_frames;
+    c->last_len = last_len;
+    if (c->timing) {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (auto &m : c->last_ms) m = 0.f;
+        for (int i = 0; i < n_marks; i++) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            c->last_ms[order_of_marks[i]] = ms;
+        }
+    }
+    return FLACGPU_OK;
+}
+
+int flacgpu_fetch(flacgpu_ctx *c, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subs,
+                  int32_t *residuals) {
+    if (!c || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
+    const size_t F = c->last_frames;
+    hipStream_t st = c->own_stream;
+    HIP_TRY(hipDeviceSynchronize());
+    if (plans) HIP_TRY(hipMemcpyAsync(plans, c->d_fplan, sizeof(*plans) * F, hipMemcpyDeviceToHost, st));
+    if (subs)
+        HIP_TRY(hipMemcpyAsync(subs, c->d_out, sizeof(*subs) * F * c->channels, hipMemcpyDeviceToHost, st));
+    if (residuals)
+        HIP_TRY(hipMemcpyAsync(residuals, c->d_resid,
+                               sizeof(int32_t) * F * c->channels * c->opts.block_size,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FLACGPU_OK;
+}
+
+int flacgpu_analyze(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32_t n_frames,
+                    uint32_t last_len, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subs,
+                    int32_t *residuals) {
+    if (!c || !pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size) {
+        g_last_error = "invalid analyze arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const size_t B = c->opts.block_size, C = c->channels;
+    const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
+    HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, c->own_stream));
+    // planar host input with a short last frame is laid out [frame][ch][len]; handled by K0
+    int rc = flacgpu_analyze_device(c, c->d_in, layout, n_frames, last_len, c->own_stream);
+    if (rc) return rc;
+    return flacgpu_fetch(c, plans, subs, residuals);
+}
+
+int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
+    if (!c || !out) return FLACGPU_ERR_INVALID_ARG;
+    uint32_t s[4];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s, c->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    out->frames = c->last_frames;
+    out->lpc_failed = s[0];
+    out->order_ties = s[1];
+    out->log2_edge = s[2];
+    return FLACGPU_OK;
+}
+
+void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
+    if (!c) return nullptr;
+    switch (which) {
+    case 0: return c->d_fplan;
+    case 1: return c->d_out;
+    case 2: return c->d_resid;
+    case 3: return c->d_planar;
+    default: return nullptr;
+    }
+}
+
+int flacgpu_get_kernel_ms(flacgpu_ctx *c, float ms[FLACGPU_N_KERNELS]) {
+    if (!c || !ms) return FLACGPU_ERR_INVALID_ARG;
+    memcpy(ms, c->last_ms, sizeof(float) * FLACGPU_N_KERNELS);
+    return FLACGPU_OK;
+}
+
+}  // extern "C"

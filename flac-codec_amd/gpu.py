@@ -1,0 +1,96 @@
+"""Thin Python handle on the analysis C ABI (include/flacenc_gpu.h).
+
+`GpuAnalyzer` replaces the analysis half of the reference's `encode_frame`
+(/root/reference/src/encode.rs:2259-2406) for a batch of frames.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FramePlan, GpuOptions, GpuStats, SubframePlan
+
+LAYOUT_INTERLEAVED, LAYOUT_PLANAR = 0, 1
+
+
+class GpuError(RuntimeError):
+    def __init__(self, code, where):
+        msg = _lib.lib().flacgpu_last_error().decode(errors="replace")
+        super().__init__(f"{where}: flacgpu error {code}: {msg}")
+        self.code = code
+
+
+class GpuAnalyzer:
+    def __init__(self, block_size, max_partition_order, max_lpc_order, mid_side, exhaustive,
+                 window_kind, window_param, bits_per_sample, channels, max_frames, device=-1):
+        L = _lib.lib()
+        o = GpuOptions(block_size, max_partition_order, max_lpc_order or 0, int(bool(mid_side)),
+                       int(bool(exhaustive)), window_kind, 0, window_param)
+        self._h = C.c_void_p(None)
+        self.block_size, self.channels, self.max_frames = block_size, channels, max_frames
+        self.bits_per_sample = bits_per_sample
+        rc = L.flacgpu_create(C.byref(o), bits_per_sample, channels, device, max_frames,
+                              C.byref(self._h))
+        if rc:
+            raise GpuError(rc, "flacgpu_create")
+
+    def close(self):
+        if self._h:
+            _lib.lib().flacgpu_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _alloc(self, n_frames):
+        plans = (FramePlan * n_frames)()
+        subs = (SubframePlan * (n_frames * self.channels))()
+        res = np.empty((n_frames, self.channels, self.block_size), dtype=np.int32)
+        return plans, subs, res
+
+    def analyze(self, pcm, n_frames, last_frame_len, layout=LAYOUT_INTERLEAVED):
+        """pcm: host int32 array.  Returns (frame plans, subframe plans, residuals)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        plans, subs, res = self._alloc(n_frames)
+        rc = _lib.lib().flacgpu_analyze(
+            self._h, pcm.ctypes.data_as(C.POINTER(C.c_int32)), layout, n_frames, last_frame_len,
+            plans, subs, res.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc:
+            raise GpuError(rc, "flacgpu_analyze")
+        return plans, subs, res
+
+    def analyze_device(self, device_ptr, n_frames, last_frame_len, layout=LAYOUT_INTERLEAVED,
+                       stream=None):
+        rc = _lib.lib().flacgpu_analyze_device(self._h, C.c_void_p(device_ptr), layout, n_frames,
+                                               last_frame_len, C.c_void_p(stream or 0))
+        if rc:
+            raise GpuError(rc, "flacgpu_analyze_device")
+
+    def fetch(self, n_frames, want_residuals=True):
+        plans, subs, res = self._alloc(n_frames)
+        rc = _lib.lib().flacgpu_fetch(
+            self._h, plans, subs,
+            res.ctypes.data_as(C.POINTER(C.c_int32)) if want_residuals else None)
+        if rc:
+            raise GpuError(rc, "flacgpu_fetch")
+        return plans, subs, res
+
+    def stats(self):
+        s = GpuStats()
+        rc = _lib.lib().flacgpu_get_stats(self._h, C.byref(s))
+        if rc:
+            raise GpuError(rc, "flacgpu_get_stats")
+        return s
+
+    def set_timing(self, on=True):
+        _lib.lib().flacgpu_set_timing(self._h, int(on))
+
+    def kernel_ms(self):
+        arr = (C.c_float * _lib.N_KERNELS)()
+        _lib.lib().flacgpu_get_kernel_ms(self._h, C.byref(arr))
+        L = _lib.lib()
+        return {L.flacgpu_kernel_name(i).decode(): float(arr[i]) for i in range(_lib.N_KERNELS)
+                if arr[i] > 0}

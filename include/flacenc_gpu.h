@@ -1,0 +1,175 @@
+/*
+ * flacenc_gpu.h -- C ABI of the MI355X-native FLAC encode hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (tuffy/flac-codec 1.3.2) is 100 % safe Rust with no FFI, so the boundary is
+ * the narrowest internal call that separates per-frame ANALYSIS from stream
+ * bookkeeping: the analysis half of `encode_frame`
+ * (/root/reference/src/encode.rs:2259-2406) -- i.e. correlate_channels[_exhaustive]
+ * (:2463-2847), encode_subframe (:2849-2980), encode_fixed_subframe (:3020-3088),
+ * LpcParameters::best / encode_residuals (:3145-3332), write_residuals' partition
+ * search (:3747-3962) -- for a BATCH of frames instead of one.  In the reference
+ * the result of that half is up to 8 `BitRecorder`s per frame; here it is a
+ * decision record per subframe plus the residual signal, or (flacgpu_pack_*) the
+ * finished frame bytes.
+ *
+ * A Rust maintainer binds these with `extern "C"` inside `Encoder::encode`
+ * (encode.rs:1997-2022); see INTEGRATION.md for the stub.
+ *
+ * Plain pointers and sizes only.  All functions return 0 on success or a
+ * negative FLACGPU_ERR_*.  A context is NOT thread-safe (one per stream or per
+ * GPU shard of a stream), exactly like the reference's `&mut Encoder`.
+ * Internal analysis failures of the reference (InsufficientLpcSamples,
+ * NoBestLpcOrder, ZeroLpCoefficients, LpNegativeShiftError, ResidualOverflow)
+ * are never surfaced: as in encode.rs:2929-2968 they only steer the
+ * FIXED / VERBATIM fallback.
+ */
+#ifndef FLACENC_GPU_H
+#define FLACENC_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACGPU_MAX_CHANNELS 8
+#define FLACGPU_MAX_LPC_ORDER 32
+#define FLACGPU_MAX_PARTITIONS 64
+#define FLACGPU_MAX_BLOCK_SIZE 16384 /* LDS-resident block; larger blocks: FLACGPU_ERR_UNSUPPORTED */
+
+enum {
+    FLACGPU_OK = 0,
+    FLACGPU_ERR_INVALID_ARG = -1,
+    FLACGPU_ERR_UNSUPPORTED = -2, /* legal for the reference but not for this build (or the
+                                     reference itself would panic, e.g. > 64 partitions,
+                                     encode.rs:3756/3880) */
+    FLACGPU_ERR_HIP = -3,         /* HIP runtime failure; flacgpu_last_error() has the text */
+    FLACGPU_ERR_NO_DEVICE = -4,
+    FLACGPU_ERR_BUFFER_TOO_SMALL = -5
+};
+
+/* encode.rs:1713-1720 `Window` */
+enum { FLACGPU_WINDOW_RECTANGLE = 0, FLACGPU_WINDOW_HANN = 1, FLACGPU_WINDOW_TUKEY = 2 };
+
+/* Mirror of `EncoderOptions` (encode.rs:1701-1709) + Options::block_size (:1366).
+ * use_rice2 is derived exactly like encode.rs:1965 (stream bits_per_sample > 16). */
+typedef struct {
+    uint32_t block_size;          /* 16..=FLACGPU_MAX_BLOCK_SIZE */
+    uint32_t max_partition_order; /* 0..=15 (effective order is capped at 6, see above) */
+    uint32_t max_lpc_order;       /* 0 = None, else 1..=32 */
+    uint8_t mid_side;
+    uint8_t exhaustive_channel_correlation;
+    uint8_t window_kind;          /* FLACGPU_WINDOW_* */
+    uint8_t reserved;
+    float window_param;           /* Tukey p */
+} flacgpu_options;
+
+/* subframe types (stream.rs:1452-1460) */
+enum { FLACGPU_SUB_CONSTANT = 0, FLACGPU_SUB_VERBATIM = 1, FLACGPU_SUB_FIXED = 2, FLACGPU_SUB_LPC = 3 };
+
+/* channel assignment as coded in the frame header (stream.rs:996-1010) */
+enum {
+    FLACGPU_ASSIGN_INDEPENDENT = 0,
+    FLACGPU_ASSIGN_LEFT_SIDE = 8,
+    FLACGPU_ASSIGN_SIDE_RIGHT = 9,
+    FLACGPU_ASSIGN_MID_SIDE = 10
+};
+
+/* candidate a subframe was computed from */
+enum { FLACGPU_SRC_MID = 8, FLACGPU_SRC_SIDE = 9 }; /* 0..7 = input channel */
+
+/* Decision record of one subframe: everything `BitRecorder::playback`
+ * (encode.rs:2332-2333) needs except the residual values themselves. */
+typedef struct {
+    uint8_t type;            /* FLACGPU_SUB_* */
+    uint8_t wasted;          /* wasted bits per sample (encode.rs:2878-2898) */
+    uint8_t bps;             /* effective bits per sample of this subframe */
+    uint8_t order;           /* FIXED 0..4 / LPC 1..32 */
+    uint8_t precision;       /* LPC coefficient precision (encode.rs:3305-3315) */
+    uint8_t shift;           /* LPC shift (encode.rs:3360) */
+    uint8_t coding_method;   /* 0 = RICE (4-bit), 1 = RICE2 (5-bit) (encode.rs:3929-3942) */
+    uint8_t partition_order; /* as written: ilog2(n_partitions) (encode.rs:3902) */
+    uint8_t source;          /* 0..7 input channel, FLACGPU_SRC_MID, FLACGPU_SRC_SIDE */
+    uint8_t reserved[3];
+    uint32_t n_partitions;   /* partitions actually emitted */
+    uint32_t part_len;       /* residual chunk length; the first chunk is short (encode.rs:3876-3879) */
+    uint32_t bits;           /* exact subframe length in bits == BitRecorder::written() */
+    int32_t coeffs[FLACGPU_MAX_LPC_ORDER];
+    uint8_t rice[FLACGPU_MAX_PARTITIONS];        /* Rice parameter; 0xFF = escaped / constant */
+    uint8_t escape_bits[FLACGPU_MAX_PARTITIONS]; /* escape size, 0 = all-zero partition */
+} flacgpu_subframe_plan;
+
+typedef struct {
+    uint8_t assignment; /* FLACGPU_ASSIGN_* */
+    uint8_t channels;
+    uint16_t block_size; /* samples per channel in this frame */
+    uint32_t body_bits;  /* sum of the subframes' bits (frame = header + ceil(body/8) + 2) */
+} flacgpu_frame_plan;
+
+/* diagnostic counters of the last analyze call */
+typedef struct {
+    uint32_t frames;
+    uint32_t lpc_failed;        /* candidates whose LPC path errored (fell back to FIXED) */
+    uint32_t order_ties;        /* candidates whose two best LPC-order estimates were within
+                                   1e-9 relative (libm-sensitive; 0 => order choice is
+                                   independent of the last-ulp behaviour of log()) */
+    uint32_t log2_edge;         /* quantise calls where max|c| sat in the libm-sensitive band
+                                   just below a power of two (handled by the host table) */
+} flacgpu_stats;
+
+typedef struct flacgpu_ctx flacgpu_ctx;
+
+/* PCM layouts accepted by analyze */
+enum {
+    FLACGPU_LAYOUT_INTERLEAVED = 0, /* [pcm_frame][channel]  (FlacSampleWriter::write, encode.rs:558) */
+    FLACGPU_LAYOUT_PLANAR = 1       /* [flac_frame][channel][block_size] (Frame, audio.rs:190-199) */
+};
+
+/* Create a context for one stream shape.  Replaces `EncodingCaches`
+ * (encode.rs:1810-1851): all scratch lives in HBM, sized for `max_frames`
+ * FLAC frames per call.  device < 0 selects the current HIP device. */
+int flacgpu_create(const flacgpu_options *opts, uint32_t bits_per_sample, uint32_t channels,
+                   int device, uint32_t max_frames, flacgpu_ctx **out);
+void flacgpu_destroy(flacgpu_ctx *ctx);
+const char *flacgpu_last_error(void);
+
+/* Analyse `n_frames` FLAC frames (all `block_size` long except the last, which is
+ * `last_frame_len` samples per channel, 1..=block_size).
+ *   pcm        host pointer, layout as given; samples must fit bits_per_sample
+ *   plans      out, [n_frames]
+ *   subframes  out, [n_frames * channels], subframe c of frame f at f*channels + c
+ *   residuals  out, [n_frames][channels][block_size] int32: for FIXED/LPC subframes the
+ *              `order` warm-up samples followed by the n-order residuals; for VERBATIM
+ *              the n samples; for CONSTANT the sample at [0] (all after wasted-bit removal)
+ * Synchronous, like the reference's encode_frame. */
+int flacgpu_analyze(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n_frames,
+                    uint32_t last_frame_len, flacgpu_frame_plan *plans,
+                    flacgpu_subframe_plan *subframes, int32_t *residuals);
+
+/* Same, PCM already resident in device memory (d_pcm is a device pointer).  Results stay
+ * on the device until flacgpu_fetch(); `stream` is a hipStream_t (NULL = default stream).
+ * Asynchronous with respect to the host. */
+int flacgpu_analyze_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                           uint32_t last_frame_len, void *stream);
+/* Copy the results of the last flacgpu_analyze_device to host buffers (any may be NULL). */
+int flacgpu_fetch(flacgpu_ctx *ctx, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subframes,
+                  int32_t *residuals);
+int flacgpu_get_stats(flacgpu_ctx *ctx, flacgpu_stats *out);
+
+/* Device pointers of the last analysis (for callers that chain further device work):
+ * which: 0 frame plans, 1 subframe plans, 2 residuals, 3 planar pcm. */
+void *flacgpu_device_buffer(flacgpu_ctx *ctx, int which);
+
+/* Duration in milliseconds of each kernel of the last analyze call, measured with HIP events
+ * on the launch stream (names via flacgpu_kernel_name).  Requires flacgpu_set_timing(ctx, 1). */
+#define FLACGPU_N_KERNELS 10
+int flacgpu_set_timing(flacgpu_ctx *ctx, int enable);
+int flacgpu_get_kernel_ms(flacgpu_ctx *ctx, float ms[FLACGPU_N_KERNELS]);
+const char *flacgpu_kernel_name(int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
