@@ -212,7 +212,10 @@ struct RiceShared {
 };
 enum { PK_STANDARD = 0, PK_ESCAPED = 1, PK_CONSTANT = 2 };
 
-__device__ void rice_search(const int32_t *r, uint32_t n, uint32_t order, const Params &p,
+// Returns false when the reference's write_residuals would fail: only possible for the
+// 31-bit escaped fallback partition (encode.rs:3887-3895) when a residual does not fit 31
+// bits (`write_signed_counted` errors, :3857) -- the subframe candidate is then an Err.
+__device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const Params &p,
                             RiceShared &S, SubPlan &plan /* LDS */, uint32_t &resid_bits) {
     const uint32_t tid = threadIdx.x;
     const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
@@ -350,7 +353,12 @@ __device__ void rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
             }
         }
     }
+    uint32_t bad = 0;
+    if (bp < 0)
+        for (uint32_t i = lo > order ? lo : order; i < hi; i++)
+            if (r[i] < -(1 << 30) || r[i] >= (1 << 30)) bad = 1;
     qsum = block_sum_u64(qsum, S.red);
+    if (bp < 0) bad = block_or_u32(bad, S.red);
     if (tid == 0) {
         const uint32_t hb = S.method ? 5u : 4u;
         uint32_t bits = 2u + 4u;  // coding method + partition order (encode.rs:3949, 3902)
@@ -379,6 +387,7 @@ __device__ void rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
     __syncthreads();
     resid_bits = S.nd_est[0];
     __syncthreads();
+    return bad == 0;
 }
 
 __device__ __forceinline__ void plan_clear(SubPlan &plan) {
@@ -634,8 +643,9 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
     }
     __syncthreads();
     uint32_t rbits;
-    rice_search(r, n, order, p, RS, plan, rbits);
+    const bool fixed_ok = rice_search(r, n, order, p, RS, plan, rbits);
     if (tid == 0) {
+        plan.reserved[0] = fixed_ok ? 0 : 1;  // internal: FIXED candidate is an Err
         plan.type = FLACGPU_SUB_FIXED;
         plan.wasted = (uint8_t)wasted;
         plan.bps = (uint8_t)bps_eff;
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
     plan_store(p.fixed_plan + cidx, plan);
     if (p.max_lpc_order == 0) {  // no LPC candidate: final choice here (encode.rs:2947-2979)
         __syncthreads();
-        const bool verbatim = !(plan.bits < n * bps_eff);
+        const bool verbatim = !fixed_ok || !(plan.bits < n * bps_eff);
         __syncthreads();
         if (verbatim) plan_clear(plan);
         __syncthreads();
@@ -966,17 +976,22 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
             if (tid == 0) atomicAdd(&p.stats[0], 1u);
         } else {
             uint32_t rbits;
-            rice_search(r, n, order, p, RS, plan, rbits);
+            if (!rice_search(r, n, order, p, RS, plan, rbits)) {
+                lpc_ok = false;
+                if (tid == 0) atomicAdd(&p.stats[0], 1u);
+            }
             lpc_bits = 8u + wasted + order * bps_eff + 4u + 5u + order * lp->precision + rbits;
         }
     }
     __syncthreads();
     const SubPlan *fx = p.fixed_plan + cidx;
     const uint32_t fixed_bits = fx->bits;
-    // (Ok,Ok) -> min_by_key(written) with FIXED first: tie keeps FIXED (encode.rs:2929-2934)
-    const bool use_lpc = lpc_ok && lpc_bits < fixed_bits;
+    const bool fixed_ok = fx->reserved[0] == 0;
+    // (Ok,Ok) -> min_by_key(written) with FIXED first: tie keeps FIXED; (Err,Ok) -> LPC;
+    // (Ok,Err) -> FIXED; (Err,Err) -> VERBATIM (encode.rs:2929-2945)
+    const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);
     const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
-    const bool verbatim = !(best_bits < n * bps_eff);  // encode.rs:2971-2979
+    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < n * bps_eff);  // :2971-2979
     if (verbatim) {
         __syncthreads();
         plan_clear(plan);
