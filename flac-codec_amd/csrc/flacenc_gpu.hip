@@ -1333,12 +1333,12 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
 
 void flacgpu_destroy(flacgpu_ctx *c) {
     if (!c) return;
-    hipFree(c->d_in); hipFree(c->d_planar); hipFree(c->d_resid); hipFree(c->d_window_full);
-    hipFree(c->d_window_last); hipFree(c->d_log2_thr); hipFree(c->d_ac); hipFree(c->d_cinfo);
-    hipFree(c->d_fixed); hipFree(c->d_cand); hipFree(c->d_out); hipFree(c->d_lpc);
-    hipFree(c->d_finfo); hipFree(c->d_fplan); hipFree(c->d_stats);
-    if (c->ev_ok) for (auto &e : c->ev) hipEventDestroy(e);
-    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    (void)hipFree(c->d_in); (void)hipFree(c->d_planar); (void)hipFree(c->d_resid); (void)hipFree(c->d_window_full);
+    (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
+    (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
+    (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
+    if (c->ev_ok) for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -1403,7 +1403,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     for (auto &u : c->ev_used) u = false;
     auto mark = [&](int k) {  // event BEFORE kernel k; the next mark closes it
         if (c->timing) {
-            hipEventRecord(c->ev[evi], st);
+            (void)hipEventRecord(c->ev[evi], st);
             c->ev_used[k] = true;
             evi++;
         }
@@ -1453,7 +1453,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
     begin(7);
     hipLaunchKernelGGL(k_emit, dim3(n_frames * c->channels), dim3(WG), dyn2 / 2, st, p);
-    if (c->timing) hipEventRecord(c->ev[evi], st);
+    if (c->timing) (void)hipEventRecord(c->ev[evi], st);
     HIP_TRY(hipGetLastError());
     c->last_frames = n_frames;
     c->last_len = last_len;
@@ -1462,7 +1462,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         for (auto &m : c->last_ms) m = 0.f;
         for (int i = 0; i < n_marks; i++) {
             float ms = 0.f;
-            hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
             c->last_ms[order_of_marks[i]] = ms;
         }
     }

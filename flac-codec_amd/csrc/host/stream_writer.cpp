@@ -1,0 +1,786 @@
+// stream_writer.cpp -- host driver: the reference's Encoder<W> + FlacSampleWriter /
+// FlacByteWriter / FlacChannelWriter / FlacStreamWriter (encode.rs:48-1290, 1853-2160),
+// batching PCM blocks into the gfx950 analysis (include/flacenc_gpu.h) and doing what the
+// reference keeps sequential: MD5, frame headers, Rice bit-packing, CRC, seek points,
+// metadata.  C ABI: include/flacenc_stream.h.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "bitsink.h"
+#include "checksums.h"
+#include "flacenc_gpu.h"
+#include "flacenc_stream.h"
+#include "frame_pack.h"
+
+namespace {
+
+using flacenc::Md5;
+
+thread_local std::string g_err;
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr uint64_t kMaxSamples = 68719476736ull;         // Encoder::MAX_SAMPLES, encode.rs:1880
+constexpr uint32_t kMaxFrameSize = (1u << 24) - 1;       // Streaminfo::MAX_FRAME_SIZE
+constexpr size_t kMaxSeekPoints = (1u << 24) / 18;       // SeekTable::MAX_POINTS
+constexpr uint64_t kMaxFrameNumber = (1ull << 36) - 1;   // FrameNumber::MAX_FRAME_NUMBER
+
+// ---- output sink (W: Write + Seek) --------------------------------------------------
+struct Sink {
+    flacenc_sink cb{};
+    bool memory = true;
+    std::vector<uint8_t> mem;
+    size_t mem_pos = 0;
+
+    int write(const uint8_t *p, size_t n) {
+        if (!memory) return cb.write(cb.user, p, n) ? FLACENC_ERR_IO : 0;
+        if (mem_pos + n > mem.size()) mem.resize(mem_pos + n);
+        std::memcpy(mem.data() + mem_pos, p, n);
+        mem_pos += n;
+        return 0;
+    }
+    int seek(uint64_t off) {
+        if (!memory) return (cb.seek && cb.seek(cb.user, off) == 0) ? 0 : FLACENC_ERR_IO;
+        mem_pos = static_cast<size_t>(off);
+        return 0;
+    }
+    uint64_t start() const { return memory ? 0 : cb.start; }
+};
+
+struct SeekPoint {
+    uint64_t sample_offset, byte_offset;
+    uint16_t frame_samples;
+    bool defined;
+};
+
+// SeekTableInterval::filter, encode.rs:1338-1358
+std::vector<SeekPoint> filter_points(const flacenc_options &o, uint32_t sample_rate,
+                                     const std::vector<SeekPoint> &in) {
+    std::vector<SeekPoint> out;
+    if (o.seektable_mode == FLACENC_SEEKTABLE_SECONDS) {
+        const uint64_t nth = static_cast<uint32_t>((o.seektable_value & 0xFFu) * sample_rate);
+        uint64_t offset = 0;
+        for (const auto &p : in)
+            if (offset >= p.sample_offset && offset < p.sample_offset + p.frame_samples) {
+                offset += nth;
+                out.push_back(p);
+            }
+    } else if (o.seektable_mode == FLACENC_SEEKTABLE_FRAMES) {
+        const size_t step = o.seektable_value ? o.seektable_value : 1;
+        for (size_t i = 0; i < in.size(); i += step) out.push_back(in[i]);
+    }
+    return out;
+}
+
+// ---- metadata serialisation (metadata/mod.rs:257-266, 904-960, 1740-1760, 1826-1831,
+//      2010-2036, 2118-2139) ----------------------------------------------------------
+struct StreamInfo {
+    uint32_t min_block = 0, max_block = 0, min_frame = 0, max_frame = 0;
+    uint32_t sample_rate = 0, channels = 0, bps = 0;
+    uint64_t total_samples = 0;  // 0 = None
+    uint8_t md5[16] = {0};
+};
+
+void put_be(std::vector<uint8_t> &v, uint64_t x, int bytes) {
+    for (int i = bytes - 1; i >= 0; i--) v.push_back(static_cast<uint8_t>(x >> (8 * i)));
+}
+void put_block_header(std::vector<uint8_t> &v, bool last, uint8_t type, uint32_t size) {
+    v.push_back(static_cast<uint8_t>((last ? 0x80 : 0) | type));
+    put_be(v, size, 3);
+}
+
+struct MetaLayout {
+    bool seektable = false;           // a SEEKTABLE block is present
+    bool seektable_after_padding = false;  // inserted at finalize => pushed last
+    std::vector<SeekPoint> points;
+    bool padding = false;
+    uint32_t padding_size = 0;
+};
+
+std::vector<uint8_t> build_metadata(const StreamInfo &si, const MetaLayout &m) {
+    std::vector<uint8_t> v;
+    v.insert(v.end(), {'f', 'L', 'a', 'C'});
+    int remaining = (m.seektable ? 1 : 0) + (m.padding ? 1 : 0);
+    put_block_header(v, remaining == 0, 0, 34);
+    put_be(v, si.min_block, 2);
+    put_be(v, si.max_block, 2);
+    put_be(v, si.min_frame, 3);
+    put_be(v, si.max_frame, 3);
+    // 20 bits rate | 3 bits channels-1 | 5 bits bps-1 | 36 bits total samples
+    uint64_t packed = (static_cast<uint64_t>(si.sample_rate) << 44) |
+                      (static_cast<uint64_t>(si.channels - 1) << 41) |
+                      (static_cast<uint64_t>(si.bps - 1) << 36) | (si.total_samples & 0xFFFFFFFFFull);
+    put_be(v, packed, 8);
+    v.insert(v.end(), si.md5, si.md5 + 16);
+    auto emit_seektable = [&]() {
+        remaining--;
+        put_block_header(v, remaining == 0, 3, static_cast<uint32_t>(m.points.size() * 18));
+        for (const auto &p : m.points) {
+            if (p.defined) {
+                put_be(v, p.sample_offset, 8);
+                put_be(v, p.byte_offset, 8);
+                put_be(v, p.frame_samples, 2);
+            } else {  // SeekPoint::Placeholder
+                put_be(v, ~0ull, 8);
+                put_be(v, 0, 8);
+                put_be(v, 0, 2);
+            }
+        }
+    };
+    auto emit_padding = [&]() {
+        remaining--;
+        put_block_header(v, remaining == 0, 1, m.padding_size);
+        v.insert(v.end(), m.padding_size, 0);
+    };
+    // block order after Encoder::new's sort (encode.rs:1944-1951): SEEKTABLE < PADDING;
+    // a SEEKTABLE created at finalize is pushed behind PADDING (metadata/mod.rs:4425-4441)
+    if (m.seektable && !m.seektable_after_padding) emit_seektable();
+    if (m.padding) emit_padding();
+    if (m.seektable && m.seektable_after_padding) emit_seektable();
+    return v;
+}
+
+int options_error(const flacenc_options &o) {
+    if (o.block_size < 16 || o.block_size > 65535) return FLACENC_ERR_INVALID_BLOCK_SIZE;
+    if (o.max_lpc_order > 32) return FLACENC_ERR_INVALID_LPC_ORDER;
+    if (o.max_partition_order > 15) return FLACENC_ERR_INVALID_MAX_PARTITIONS;
+    if (o.padding < 0 || o.padding >= (1 << 24)) return FLACENC_ERR_EXCESSIVE_PADDING;
+    return 0;
+}
+
+flacgpu_options gpu_options(const flacenc_options &o, uint32_t block_size) {
+    flacgpu_options g{};
+    g.block_size = block_size;
+    g.max_partition_order = o.max_partition_order;
+    g.max_lpc_order = o.max_lpc_order;
+    g.mid_side = o.mid_side;
+    g.exhaustive_channel_correlation = o.exhaustive_channel_correlation;
+    g.window_kind = o.window_kind;
+    g.window_param = o.window_param;
+    return g;
+}
+
+int map_gpu_error(int rc) {
+    g_err = std::string("gpu: ") + flacgpu_last_error();
+    return rc == FLACGPU_ERR_UNSUPPORTED ? FLACENC_ERR_UNSUPPORTED : FLACENC_ERR_GPU;
+}
+
+// Packs the frames of one analysed batch in parallel (frames are independent once their
+// frame numbers and sizes are known) and appends them to `out`.
+struct PackedBatch {
+    std::vector<uint8_t> bytes;
+    std::vector<size_t> offsets;  // n_frames + 1
+};
+
+int pack_batch(uint32_t sample_rate, uint32_t bps, uint32_t channels, uint64_t first_frame_number,
+               uint32_t n_frames, uint32_t row_stride, const flacgpu_frame_plan *plans,
+               const flacgpu_subframe_plan *subs, const int32_t *rows, unsigned threads,
+               PackedBatch &out) {
+    out.offsets.assign(n_frames + 1, 0);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        flacenc::FrameParams fp{sample_rate, bps, channels, first_frame_number + f};
+        out.offsets[f + 1] = out.offsets[f] + flacenc::frame_size(fp, plans[f]);
+    }
+    out.bytes.resize(out.offsets[n_frames] + 16);
+    std::vector<int> status(std::max(1u, threads), 0);
+    auto work = [&](unsigned t, unsigned nt) {
+        // contiguous frame ranges per thread; the 32-bit stores of BitSink may spill up to 3
+        // bytes into the next frame's region, so frames are packed into a scratch buffer
+        std::vector<uint8_t> scratch;
+        uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(n_frames) * t / nt);
+        uint32_t hi = static_cast<uint32_t>(static_cast<uint64_t>(n_frames) * (t + 1) / nt);
+        for (uint32_t f = lo; f < hi; f++) {
+            flacenc::FrameParams fp{sample_rate, bps, channels, first_frame_number + f};
+            const size_t sz = out.offsets[f + 1] - out.offsets[f];
+            scratch.resize(sz + 8);
+            size_t got = flacenc::pack_frame(fp, plans[f], subs + static_cast<size_t>(f) * channels,
+                                             rows + static_cast<size_t>(f) * channels * row_stride,
+                                             row_stride, scratch.data(), scratch.size());
+            if (got != sz) {
+                status[t] = 1;
+                return;
+            }
+            std::memcpy(out.bytes.data() + out.offsets[f], scratch.data(), sz);
+        }
+    };
+    unsigned nt = std::max(1u, std::min<unsigned>(threads, n_frames));
+    if (nt == 1) {
+        work(0, 1);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; t++) pool.emplace_back(work, t, nt);
+        for (auto &th : pool) th.join();
+    }
+    for (int s : status)
+        if (s) {
+            g_err = "internal: packed frame size differs from its decision record";
+            return FLACENC_ERR_GPU;
+        }
+    out.bytes.resize(out.offsets[n_frames]);
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================
+// Encoder<W>, encode.rs:1853-2110
+// =====================================================================================
+struct flacenc_writer {
+    enum Kind { SAMPLE, BYTE, CHANNEL } kind = SAMPLE;
+    flacenc_options o{};
+    Sink sink;
+    StreamInfo si;
+    MetaLayout meta;
+    size_t metadata_len = 0;
+    uint64_t frame_number = 0, samples_written = 0, byte_count = 0;  // Counter::count
+    std::vector<SeekPoint> seekpoints;
+    Md5 md5;
+    bool finalized = false;
+    flacgpu_ctx *gpu = nullptr;
+    uint32_t batch_frames = 1024;
+    unsigned pack_threads = 1;
+    // backlog of interleaved samples not yet cut into blocks (FlacSampleWriter::sample_buf)
+    std::vector<int32_t> backlog;
+    // byte writer state
+    bool big_endian = false;
+    unsigned bytes_per_sample = 2;
+    std::vector<uint8_t> byte_backlog;
+    // per-batch scratch
+    std::vector<flacgpu_frame_plan> plans;
+    std::vector<flacgpu_subframe_plan> subs;
+    std::vector<int32_t> rows;
+    std::vector<uint8_t> md5_bytes;
+    flacenc_stats stats{};
+
+    ~flacenc_writer() {
+        if (gpu) flacgpu_destroy(gpu);
+    }
+
+    // Encoder::new, encode.rs:1882-1980
+    int init(const flacenc_options &opts, uint32_t rate, uint32_t bps, uint32_t channels,
+             bool has_total, uint64_t total_pcm_frames, const flacenc_sink *s) {
+        o = opts;
+        if (int e = options_error(o)) return e;
+        if (rate >= 1048576u) return FLACENC_ERR_INVALID_SAMPLE_RATE;
+        if (channels < 1 || channels > 8) return FLACENC_ERR_EXCESSIVE_CHANNELS;
+        if (has_total && total_pcm_frames >= kMaxSamples) return FLACENC_ERR_EXCESSIVE_TOTAL_SAMPLES;
+        if (s) {
+            sink.memory = false;
+            sink.cb = *s;
+        }
+        si.min_block = si.max_block = o.block_size;
+        si.sample_rate = rate;
+        si.channels = channels;
+        si.bps = bps;
+        si.total_samples = has_total ? total_pcm_frames : 0;
+        bytes_per_sample = (bps + 7) / 8;
+        meta.padding = o.padding > 0;
+        meta.padding_size = static_cast<uint32_t>(o.padding);
+        if (has_total && o.seektable_mode != FLACENC_SEEKTABLE_NONE) {
+            // placeholder SEEKTABLE, encode.rs:1920-1939 + EncoderSeekPoint::placeholders :2131
+            std::vector<SeekPoint> all;
+            for (uint64_t off = 0; off < total_pcm_frames; off += o.block_size) {
+                uint64_t rem = total_pcm_frames - off;
+                uint16_t fs = static_cast<uint16_t>(rem > 65535 ? o.block_size
+                                                                 : std::min<uint64_t>(rem, o.block_size));
+                all.push_back({off, 0, fs, false});
+            }
+            meta.points = filter_points(o, rate, all);
+            if (meta.points.size() > kMaxSeekPoints) meta.points.resize(kMaxSeekPoints);
+            for (auto &p : meta.points) p.defined = false;
+            meta.seektable = true;
+        }
+        std::vector<uint8_t> hdr = build_metadata(si, meta);
+        metadata_len = hdr.size();
+        if (int e = sink.write(hdr.data(), hdr.size())) return e;
+        batch_frames = o.batch_frames ? o.batch_frames : 1024;
+        unsigned hw = std::thread::hardware_concurrency();
+        pack_threads = o.pack_threads ? o.pack_threads : std::max(1u, std::min(hw, 16u));
+        flacgpu_options g = gpu_options(o, o.block_size);
+        int rc = flacgpu_create(&g, bps, channels, o.device, batch_frames, &gpu);
+        if (rc) return map_gpu_error(rc);
+        return 0;
+    }
+
+    // update_md5, encode.rs:1292-1318: little-endian, ceil(bps/8) bytes per sample
+    void md5_samples(const int32_t *s, size_t count) {
+        double t0 = now_ms();
+        md5_bytes.resize(count * bytes_per_sample);
+        uint8_t *d = md5_bytes.data();
+        switch (bytes_per_sample) {
+        case 1: for (size_t i = 0; i < count; i++) d[i] = static_cast<uint8_t>(s[i]); break;
+        case 2:
+            for (size_t i = 0; i < count; i++) {
+                uint32_t v = static_cast<uint32_t>(s[i]);
+                d[2 * i] = static_cast<uint8_t>(v);
+                d[2 * i + 1] = static_cast<uint8_t>(v >> 8);
+            }
+            break;
+        case 3:
+            for (size_t i = 0; i < count; i++) {
+                uint32_t v = static_cast<uint32_t>(s[i]);
+                d[3 * i] = static_cast<uint8_t>(v);
+                d[3 * i + 1] = static_cast<uint8_t>(v >> 8);
+                d[3 * i + 2] = static_cast<uint8_t>(v >> 16);
+            }
+            break;
+        default: std::memcpy(d, s, count * 4); break;
+        }
+        md5.update(d, md5_bytes.size());
+        stats.md5_ms += now_ms() - t0;
+    }
+
+    // Encoder::encode for a run of blocks (encode.rs:1997-2022 + encode_frame's tail
+    // :2408-2436), `n_frames` blocks of block_size, the last one `last_len` long.
+    int encode_blocks(const int32_t *interleaved, uint32_t n_frames, uint32_t last_len) {
+        const uint32_t B = o.block_size, C = si.channels;
+        plans.resize(n_frames);
+        subs.resize(static_cast<size_t>(n_frames) * C);
+        rows.resize(static_cast<size_t>(n_frames) * C * B);
+        // ExcessiveTotalSamples is raised BEFORE the offending frame is encoded (:2006-2011)
+        uint32_t usable = n_frames;
+        int deferred = 0;
+        if (si.total_samples) {
+            uint64_t w = samples_written;
+            for (uint32_t f = 0; f < n_frames; f++) {
+                w += (f + 1 == n_frames) ? last_len : B;
+                if (w > si.total_samples) {
+                    usable = f;
+                    deferred = FLACENC_ERR_EXCESSIVE_TOTAL_SAMPLES;
+                    break;
+                }
+            }
+        }
+        if (usable) {
+            const uint32_t ll = (usable == n_frames) ? last_len : B;
+            double t0 = now_ms();
+            int rc = flacgpu_analyze(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
+                                     plans.data(), subs.data(), rows.data());
+            stats.gpu_ms += now_ms() - t0;
+            if (rc) return map_gpu_error(rc);
+            if (frame_number + usable - 1 > kMaxFrameNumber) return FLACENC_ERR_EXCESSIVE_FRAME_NUMBER;
+            t0 = now_ms();
+            PackedBatch pb;
+            if (int e = pack_batch(si.sample_rate, si.bps, C, frame_number, usable, B, plans.data(),
+                                   subs.data(), rows.data(), pack_threads, pb))
+                return e;
+            stats.pack_ms += now_ms() - t0;
+            for (uint32_t f = 0; f < usable; f++) {
+                const uint32_t n = plans[f].block_size;
+                seekpoints.push_back({samples_written, byte_count + pb.offsets[f], static_cast<uint16_t>(n), true});
+                samples_written += n;
+                const uint32_t size = static_cast<uint32_t>(pb.offsets[f + 1] - pb.offsets[f]);
+                if (size != 0 && size < kMaxFrameSize) {  // :2414-2436
+                    si.min_frame = si.min_frame ? std::min(si.min_frame, size) : size;
+                    si.max_frame = std::max(si.max_frame, size);
+                }
+            }
+            frame_number += usable;
+            byte_count += pb.bytes.size();
+            if (int e = sink.write(pb.bytes.data(), pb.bytes.size())) return e;
+        }
+        if (deferred) {
+            // the reference pushes the seekpoint and bumps samples_written before failing
+            seekpoints.push_back({samples_written, byte_count, static_cast<uint16_t>(B), true});
+            samples_written += (usable + 1 == n_frames) ? last_len : B;
+        }
+        return deferred;
+    }
+
+    // cut whole blocks out of the backlog, batch by batch
+    int drain(bool final_flush) {
+        const size_t frame_samples = static_cast<size_t>(o.block_size) * si.channels;
+        size_t consumed = 0;
+        int rc = 0;
+        while (rc == 0) {
+            size_t whole = (backlog.size() - consumed) / frame_samples;
+            if (whole == 0) break;
+            if (!final_flush && whole < batch_frames) break;  // wait for a full batch
+            uint32_t take = static_cast<uint32_t>(std::min<size_t>(whole, batch_frames));
+            const int32_t *src = backlog.data() + consumed;
+            md5_samples(src, take * frame_samples);
+            rc = encode_blocks(src, take, o.block_size);
+            consumed += take * frame_samples;
+        }
+        if (consumed) backlog.erase(backlog.begin(), backlog.begin() + static_cast<ptrdiff_t>(consumed));
+        return rc;
+    }
+
+    // FlacSampleWriter::finalize_inner, encode.rs:588-611, then Encoder::finalize_inner :2024
+    int finalize() {
+        if (finalized) return 0;
+        finalized = true;
+        // FlacByteWriter keeps raw bytes; bytes that do not make a whole sample are dropped by
+        // the truncation to whole PCM frames (encode.rs:263-265)
+        const bool had_partial_sample = !byte_backlog.empty();
+        byte_backlog.clear();
+        int rc = drain(true);
+        if (rc) return rc;
+        if (backlog.empty() && had_partial_sample) {
+            g_err = "final partial block holds less than one PCM frame (the reference panics)";
+            return FLACENC_ERR_UNSUPPORTED;
+        }
+        if (!backlog.empty()) {
+            size_t usable = backlog.size() - backlog.size() % si.channels;
+            if (usable == 0) {
+                // Frame with zero PCM frames: `chunks_exact(0)` panics in the reference
+                // (audio.rs:177 via encode.rs:2020); surfaced as an error here
+                g_err = "final partial block holds less than one PCM frame (the reference panics)";
+                return FLACENC_ERR_UNSUPPORTED;
+            }
+            md5_samples(backlog.data(), usable);
+            rc = encode_blocks(backlog.data(), 1, static_cast<uint32_t>(usable / si.channels));
+            backlog.clear();
+            if (rc) return rc;
+        }
+        return finalize_encoder();
+    }
+
+    int finalize_encoder() {
+        // SEEKTABLE, encode.rs:2029-2076
+        if (o.seektable_mode != FLACENC_SEEKTABLE_NONE) {
+            std::vector<SeekPoint> enc = filter_points(o, si.sample_rate, seekpoints);
+            if (meta.seektable) {
+                const size_t n = meta.points.size();
+                for (size_t i = 0; i < n; i++) {
+                    if (i < enc.size()) meta.points[i] = enc[i];
+                    else meta.points[i] = SeekPoint{0, 0, 0, false};
+                }
+            } else if (meta.padding) {
+                if (enc.size() > kMaxSeekPoints) {
+                    g_err = "more seek points than a SEEKTABLE holds (the reference panics)";
+                    return FLACENC_ERR_UNSUPPORTED;
+                }
+                const uint64_t st_total = static_cast<uint64_t>(enc.size()) * 18 + 4;
+                if (enc.size() * 18 < (1u << 24) && meta.padding_size >= st_total) {
+                    meta.padding_size -= static_cast<uint32_t>(st_total);
+                    meta.points = enc;
+                    meta.seektable = true;
+                    meta.seektable_after_padding = true;
+                }
+            }
+        }
+        // total samples, encode.rs:2079-2097
+        if (si.total_samples) {
+            if (si.total_samples != samples_written) return FLACENC_ERR_SAMPLE_COUNT_MISMATCH;
+        } else {
+            if (samples_written >= kMaxSamples) return FLACENC_ERR_EXCESSIVE_TOTAL_SAMPLES;
+            if (samples_written == 0) return FLACENC_ERR_NO_SAMPLES;
+            si.total_samples = samples_written;
+        }
+        md5.digest(si.md5);
+        std::vector<uint8_t> hdr = build_metadata(si, meta);
+        if (hdr.size() != metadata_len) {
+            g_err = "internal: metadata size changed at finalize";
+            return FLACENC_ERR_IO;
+        }
+        if (int e = sink.seek(sink.start())) return e;
+        if (int e = sink.write(hdr.data(), hdr.size())) return e;
+        if (sink.memory) sink.mem_pos = sink.mem.size();
+        stats.frames = frame_number;
+        stats.samples_per_channel = samples_written;
+        stats.bytes_written = metadata_len + byte_count;
+        stats.min_frame_size = si.min_frame;
+        stats.max_frame_size = si.max_frame;
+        std::memcpy(stats.md5, si.md5, 16);
+        return 0;
+    }
+
+    // Endianness::bytes_to_le + Frame::fill_from_buf (byteorder.rs, audio.rs:149-188)
+    void append_bytes_as_samples(const uint8_t *p, size_t nbytes) {
+        const unsigned b = bytes_per_sample;
+        const size_t count = nbytes / b;
+        const size_t base = backlog.size();
+        backlog.resize(base + count);
+        int32_t *d = backlog.data() + base;
+        for (size_t i = 0; i < count; i++) {
+            uint32_t v = 0;
+            if (big_endian)
+                for (unsigned k = 0; k < b; k++) v = (v << 8) | p[i * b + k];
+            else
+                for (unsigned k = 0; k < b; k++) v |= static_cast<uint32_t>(p[i * b + k]) << (8 * k);
+            const unsigned sh = 32 - 8 * b;
+            d[i] = static_cast<int32_t>(v << sh) >> sh;  // sign-extend
+        }
+    }
+};
+
+extern "C" {
+
+const char *flacenc_last_error(void) { return g_err.c_str(); }
+
+void flacenc_options_default(flacenc_options *o) {  // encode.rs:1376-1408
+    std::memset(o, 0, sizeof *o);
+    o->block_size = 4096;
+    o->max_partition_order = 5;
+    o->max_lpc_order = 8;
+    o->mid_side = 1;
+    o->exhaustive_channel_correlation = 1;
+    o->window_kind = FLACGPU_WINDOW_TUKEY;
+    o->window_param = 0.5f;
+    o->padding = 4096;
+    o->seektable_mode = FLACENC_SEEKTABLE_SECONDS;
+    o->seektable_value = 10;
+    o->device = -1;
+}
+void flacenc_options_fast(flacenc_options *o) {  // encode.rs:1635-1644
+    flacenc_options_default(o);
+    o->block_size = 1152;
+    o->mid_side = 0;
+    o->max_partition_order = 3;
+    o->max_lpc_order = 0;
+    o->exhaustive_channel_correlation = 0;
+}
+void flacenc_options_best(flacenc_options *o) {  // encode.rs:1649-1657
+    flacenc_options_default(o);
+    o->block_size = 4096;
+    o->mid_side = 1;
+    o->max_partition_order = 6;
+    o->max_lpc_order = 12;
+}
+int flacenc_options_validate(const flacenc_options *o) { return o ? options_error(*o) : FLACENC_ERR_INVALID_ARG; }
+
+static int new_writer(flacenc_writer::Kind kind, const flacenc_options *opts, uint32_t rate,
+                      uint32_t bps, uint32_t channels, bool has_total, uint64_t total_pcm_frames,
+                      bool big_endian, const flacenc_sink *sink, flacenc_writer **out) {
+    std::unique_ptr<flacenc_writer> w(new flacenc_writer());
+    w->kind = kind;
+    w->big_endian = big_endian;
+    int rc = w->init(*opts, rate, bps, channels, has_total, total_pcm_frames, sink);
+    if (rc) return rc;
+    *out = w.release();
+    return 0;
+}
+
+int flacenc_sample_writer_new(const flacenc_options *opts, uint32_t rate, uint32_t bps,
+                              uint32_t channels, int has_total, uint64_t total_samples,
+                              const flacenc_sink *sink, flacenc_writer **out) {
+    if (!opts || !out) return FLACENC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bps < 1 || bps > 32) return FLACENC_ERR_INVALID_BITS_PER_SAMPLE;  // encode.rs:495
+    uint64_t pcm_frames = 0;
+    if (has_total) {  // encode.rs:513-519
+        if (channels == 0 || total_samples % channels) return FLACENC_ERR_SAMPLES_NOT_DIVISIBLE_BY_CHANNELS;
+        pcm_frames = total_samples / channels;
+        if (pcm_frames == 0) return FLACENC_ERR_INVALID_TOTAL_SAMPLES;
+    }
+    return new_writer(flacenc_writer::SAMPLE, opts, rate, bps, channels, has_total, pcm_frames, false, sink, out);
+}
+
+int flacenc_byte_writer_new(const flacenc_options *opts, uint32_t rate, uint32_t bps,
+                            uint32_t channels, int has_total, uint64_t total_bytes, int big_endian,
+                            const flacenc_sink *sink, flacenc_writer **out) {
+    if (!opts || !out) return FLACENC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bps < 1 || bps > 32) return FLACENC_ERR_INVALID_BITS_PER_SAMPLE;
+    uint64_t pcm_frames = 0;
+    if (has_total) {  // encode.rs:171-178
+        const uint64_t bytes_per_sample = (bps + 7) / 8;
+        if (channels == 0 || total_bytes % channels || (total_bytes / channels) % bytes_per_sample)
+            return FLACENC_ERR_SAMPLES_NOT_DIVISIBLE_BY_CHANNELS;
+        pcm_frames = total_bytes / channels / bytes_per_sample;
+        if (pcm_frames == 0) return FLACENC_ERR_INVALID_TOTAL_BYTES;
+    }
+    return new_writer(flacenc_writer::BYTE, opts, rate, bps, channels, has_total, pcm_frames,
+                      big_endian != 0, sink, out);
+}
+
+int flacenc_channel_writer_new(const flacenc_options *opts, uint32_t rate, uint32_t bps,
+                               uint32_t channels, int has_total, uint64_t total_samples,
+                               const flacenc_sink *sink, flacenc_writer **out) {
+    if (!opts || !out) return FLACENC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bps < 1 || bps > 32) return FLACENC_ERR_INVALID_BITS_PER_SAMPLE;
+    // total_samples.and_then(NonZero::new): Some(0) behaves like None (encode.rs:797)
+    bool ht = has_total && total_samples != 0;
+    return new_writer(flacenc_writer::CHANNEL, opts, rate, bps, channels, ht, total_samples, false, sink, out);
+}
+
+int flacenc_write_samples(flacenc_writer *w, const int32_t *samples, size_t count) {
+    if (!w || (!samples && count)) return FLACENC_ERR_INVALID_ARG;
+    if (w->finalized) return FLACENC_ERR_FINALIZED;
+    w->backlog.insert(w->backlog.end(), samples, samples + count);
+    return w->drain(false);
+}
+
+int flacenc_write_bytes(flacenc_writer *w, const uint8_t *bytes, size_t count) {
+    if (!w || (!bytes && count)) return FLACENC_ERR_INVALID_ARG;
+    if (w->finalized) return FLACENC_ERR_FINALIZED;
+    // keep bytes that do not yet make a whole sample; everything else becomes samples
+    w->byte_backlog.insert(w->byte_backlog.end(), bytes, bytes + count);
+    const size_t usable = w->byte_backlog.size() - w->byte_backlog.size() % w->bytes_per_sample;
+    w->append_bytes_as_samples(w->byte_backlog.data(), usable);
+    w->byte_backlog.erase(w->byte_backlog.begin(), w->byte_backlog.begin() + static_cast<ptrdiff_t>(usable));
+    return w->drain(false);
+}
+
+int flacenc_write_channels(flacenc_writer *w, const int32_t *const *channels, uint32_t n_channels,
+                           size_t len) {
+    if (!w || !channels) return FLACENC_ERR_INVALID_ARG;
+    if (w->finalized) return FLACENC_ERR_FINALIZED;
+    if (n_channels != w->si.channels) return FLACENC_ERR_CHANNEL_COUNT_MISMATCH;  // encode.rs:856-859
+    const size_t base = w->backlog.size();
+    w->backlog.resize(base + len * n_channels);
+    int32_t *d = w->backlog.data() + base;
+    for (uint32_t c = 0; c < n_channels; c++)
+        for (size_t i = 0; i < len; i++) d[i * n_channels + c] = channels[c][i];
+    return w->drain(false);
+}
+
+int flacenc_finalize(flacenc_writer *w) {
+    if (!w) return FLACENC_ERR_INVALID_ARG;
+    return w->finalize();
+}
+
+void flacenc_writer_free(flacenc_writer *w) {
+    if (!w) return;
+    (void)w->finalize();  // Drop: finalize, ignoring errors (encode.rs:399-405, 2113-2117)
+    delete w;
+}
+
+const uint8_t *flacenc_writer_data(flacenc_writer *w, size_t *len) {
+    if (!w || !w->sink.memory) {
+        if (len) *len = 0;
+        return nullptr;
+    }
+    if (len) *len = w->sink.mem.size();
+    return w->sink.mem.data();
+}
+
+int flacenc_pack_frames(uint32_t sample_rate, uint32_t bps, uint32_t channels,
+                        uint64_t first_frame_number, uint32_t n_frames, uint32_t row_stride,
+                        const void *frame_plans, const void *subframe_plans,
+                        const int32_t *residual_rows, uint32_t threads, uint8_t *out, size_t cap,
+                        uint64_t *offsets) {
+    if (!frame_plans || !subframe_plans || !residual_rows || !offsets || n_frames == 0)
+        return FLACENC_ERR_INVALID_ARG;
+    PackedBatch pb;
+    int rc = pack_batch(sample_rate, bps, channels, first_frame_number, n_frames, row_stride,
+                        static_cast<const flacgpu_frame_plan *>(frame_plans),
+                        static_cast<const flacgpu_subframe_plan *>(subframe_plans), residual_rows,
+                        threads ? threads : 1, pb);
+    if (rc) return rc;
+    for (uint32_t f = 0; f <= n_frames; f++) offsets[f] = pb.offsets[f];
+    if (!out || cap < pb.bytes.size()) return FLACENC_ERR_INVALID_ARG;
+    std::memcpy(out, pb.bytes.data(), pb.bytes.size());
+    return 0;
+}
+
+int flacenc_writer_stats(flacenc_writer *w, flacenc_stats *out) {
+    if (!w || !out) return FLACENC_ERR_INVALID_ARG;
+    *out = w->stats;
+    return 0;
+}
+
+}  // extern "C"
+
+// =====================================================================================
+// FlacStreamWriter, encode.rs:1050-1290: subset frames, no metadata, parameters per call
+// =====================================================================================
+struct flacenc_stream_writer {
+    flacenc_options o{};
+    Sink sink;
+    uint64_t frame_number = 0;
+    struct Key {
+        uint32_t bps, channels, cap;
+        bool operator<(const Key &k) const {
+            return std::tie(bps, channels, cap) < std::tie(k.bps, k.channels, k.cap);
+        }
+    };
+    std::map<Key, flacgpu_ctx *> ctxs;
+    ~flacenc_stream_writer() {
+        for (auto &kv : ctxs) flacgpu_destroy(kv.second);
+    }
+};
+
+extern "C" {
+
+int flacenc_stream_writer_new(const flacenc_options *opts, const flacenc_sink *sink,
+                              flacenc_stream_writer **out) {
+    if (!opts || !out) return FLACENC_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (int e = options_error(*opts)) return e;
+    auto *w = new flacenc_stream_writer();
+    w->o = *opts;
+    if (sink) {
+        w->sink.memory = false;
+        w->sink.cb = *sink;
+    }
+    *out = w;
+    return 0;
+}
+
+int flacenc_stream_writer_write(flacenc_stream_writer *w, uint32_t rate, uint32_t channels,
+                                uint32_t bps, const int32_t *samples, size_t count) {
+    if (!w || (!samples && count)) return FLACENC_ERR_INVALID_ARG;
+    // validation order of encode.rs:1151-1191
+    if (bps < 1 || bps > 32) return FLACENC_ERR_NON_SUBSET_BITS_PER_SAMPLE;
+    if (channels == 0 || count % channels) return FLACENC_ERR_SAMPLES_NOT_DIVISIBLE_BY_CHANNELS;
+    if (channels > 8) return FLACENC_ERR_EXCESSIVE_CHANNELS;
+    const size_t n = count / channels;
+    if (n == 0 || n > 65535) return FLACENC_ERR_INVALID_BLOCK_SIZE;
+    {  // SampleRate::try_from + "Streaminfo => NonSubsetSampleRate"
+        bool named = false;
+        for (uint32_t r : {88200u, 176400u, 192000u, 8000u, 16000u, 22050u, 24000u, 32000u, 44100u, 48000u, 96000u})
+            named |= (r == rate);
+        bool coded = named || (rate % 1000 == 0 && rate / 1000 < 255) ||
+                     (rate % 10 == 0 && rate / 10 < 65535) || rate < 65535;
+        if (!coded) return rate < (1u << 20) ? FLACENC_ERR_NON_SUBSET_SAMPLE_RATE : FLACENC_ERR_INVALID_SAMPLE_RATE;
+    }
+    if (!(bps == 8 || bps == 12 || bps == 16 || bps == 20 || bps == 24 || bps == 32))
+        return FLACENC_ERR_NON_SUBSET_BITS_PER_SAMPLE;
+    uint32_t cap = 16;
+    while (cap < n) cap <<= 1;
+    if (cap > FLACGPU_MAX_BLOCK_SIZE) {
+        g_err = "block larger than FLACGPU_MAX_BLOCK_SIZE";
+        return FLACENC_ERR_UNSUPPORTED;
+    }
+    flacenc_stream_writer::Key key{bps, channels, cap};
+    flacgpu_ctx *ctx = nullptr;
+    auto it = w->ctxs.find(key);
+    if (it == w->ctxs.end()) {
+        flacgpu_options g = gpu_options(w->o, cap);
+        int rc = flacgpu_create(&g, bps, channels, w->o.device, 1, &ctx);
+        if (rc) return map_gpu_error(rc);
+        w->ctxs[key] = ctx;
+    } else {
+        ctx = it->second;
+    }
+    flacgpu_frame_plan plan;
+    std::vector<flacgpu_subframe_plan> subs(channels);
+    std::vector<int32_t> rows(static_cast<size_t>(channels) * cap);
+    int rc = flacgpu_analyze(ctx, samples, FLACGPU_LAYOUT_INTERLEAVED, 1, static_cast<uint32_t>(n),
+                             &plan, subs.data(), rows.data());
+    if (rc) return map_gpu_error(rc);
+    PackedBatch pb;
+    if (int e = pack_batch(rate, bps, channels, w->frame_number, 1, cap, &plan, subs.data(), rows.data(), 1, pb))
+        return e;
+    if (int e = w->sink.write(pb.bytes.data(), pb.bytes.size())) return e;
+    if (w->frame_number >= kMaxFrameNumber) return FLACENC_ERR_EXCESSIVE_FRAME_NUMBER;
+    w->frame_number++;
+    return 0;
+}
+
+const uint8_t *flacenc_stream_writer_data(flacenc_stream_writer *w, size_t *len) {
+    if (!w || !w->sink.memory) {
+        if (len) *len = 0;
+        return nullptr;
+    }
+    if (len) *len = w->sink.mem.size();
+    return w->sink.mem.data();
+}
+
+void flacenc_stream_writer_free(flacenc_stream_writer *w) { delete w; }
+
+}  // extern "C"
