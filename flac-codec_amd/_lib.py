@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libflacenc_amd.so")
 MAX_CHANNELS = 8
 MAX_LPC_ORDER = 32
 MAX_PARTITIONS = 64
-N_KERNELS = 10
+N_KERNELS = 12
 
 
 class GpuOptions(C.Structure):
@@ -103,6 +103,15 @@ def lib():
     L.flacgpu_device_buffer.restype = vp
     L.flacgpu_set_timing.argtypes = [vp, C.c_int]
     L.flacgpu_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * N_KERNELS)]
+    L.flacgpu_pack_device.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
+    L.flacgpu_fetch_frames.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]
+    L.flacgpu_encode_frames.argtypes = [vp, ip, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64,
+                                        C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64)]
+    L.flacenc_pack_frames.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+                                      C.c_uint32, C.c_void_p, C.c_void_p, ip, C.c_uint32,
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]
     L.flacgpu_kernel_name.restype = C.c_char_p
     _lib = L

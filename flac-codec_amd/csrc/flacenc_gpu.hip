@@ -1126,12 +1126,386 @@ __global__ void __launch_bounds__(WG) k_emit(Params p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Device-side frame assembly.
+//   K8  k_layout  frame sizes (header + ceil(body/8) + 2) -> exclusive prefix sum
+//   K9  k_pack    one workgroup per (frame, subframe): the subframe's bits are built in LDS
+//                 (header, warm-up, LPC parameters by a few lanes; residual codes at bit
+//                 offsets from a workgroup prefix scan of the code lengths) and copied to
+//                 the frame's position in HBM with a funnel shift; words shared with a
+//                 neighbouring subframe / frame are OR-ed atomically (the buffer is zeroed
+//                 first, so byte-alignment padding is free)
+//   K10 k_crc     CRC-16 of every frame: 256 lanes each fold a slice, partial CRCs are
+//                 combined with x^(8*len) mod P multiplications (GF(2) linearity)
+// Replaces stream.rs:242-276 (FrameHeader::build + CRC-8), stream.rs:1390-1413,
+// 1603-1619, encode.rs:3078-3135 (subframe serialisation), 3834-3907 (residual block),
+// 2408-2409 (align + CRC-16).
+// ---------------------------------------------------------------------------------
+struct PackParams {
+    uint64_t first_frame_number;
+    uint32_t sample_rate;
+    uint32_t *out_words;      // packed bytes, viewed as big-endian-filled 32-bit words
+    uint64_t *frame_off;      // [n_frames + 1] byte offsets
+    uint64_t cap_bytes;
+};
+
+struct HeaderCodes {
+    uint32_t bcode, bextra_bits, rcode, rextra_bits, rextra, fn_bytes;
+};
+__device__ __forceinline__ HeaderCodes header_codes(uint32_t n, uint32_t rate, uint64_t fn) {
+    HeaderCodes h;
+    h.bextra_bits = 0;
+    switch (n) {  // BlockSize::try_from, stream.rs:531-558
+    case 192: h.bcode = 1; break;
+    case 576: h.bcode = 2; break;
+    case 1152: h.bcode = 3; break;
+    case 2304: h.bcode = 4; break;
+    case 4608: h.bcode = 5; break;
+    case 256: h.bcode = 8; break;
+    case 512: h.bcode = 9; break;
+    case 1024: h.bcode = 10; break;
+    case 2048: h.bcode = 11; break;
+    case 4096: h.bcode = 12; break;
+    case 8192: h.bcode = 13; break;
+    case 16384: h.bcode = 14; break;
+    case 32768: h.bcode = 15; break;
+    default:
+        if (n <= 256) { h.bcode = 6; h.bextra_bits = 8; }
+        else { h.bcode = 7; h.bextra_bits = 16; }
+    }
+    h.rextra_bits = 0;
+    h.rextra = 0;
+    switch (rate) {  // SampleRate::try_from, stream.rs:767-800
+    case 88200: h.rcode = 1; break;
+    case 176400: h.rcode = 2; break;
+    case 192000: h.rcode = 3; break;
+    case 8000: h.rcode = 4; break;
+    case 16000: h.rcode = 5; break;
+    case 22050: h.rcode = 6; break;
+    case 24000: h.rcode = 7; break;
+    case 32000: h.rcode = 8; break;
+    case 44100: h.rcode = 9; break;
+    case 48000: h.rcode = 10; break;
+    case 96000: h.rcode = 11; break;
+    default:
+        if (rate % 1000 == 0 && rate / 1000 < 255) { h.rcode = 12; h.rextra_bits = 8; h.rextra = rate / 1000; }
+        else if (rate % 10 == 0 && rate / 10 < 65535) { h.rcode = 14; h.rextra_bits = 16; h.rextra = rate / 10; }
+        else if (rate < 65535) { h.rcode = 13; h.rextra_bits = 16; h.rextra = rate; }
+        else h.rcode = 0;
+    }
+    h.fn_bytes = fn <= 0x7F ? 1 : fn <= 0x7FF ? 2 : fn <= 0xFFFF ? 3 : fn <= 0x1FFFFF ? 4
+               : fn <= 0x3FFFFFF ? 5 : fn <= 0x7FFFFFFFull ? 6 : 7;
+    return h;
+}
+__device__ __forceinline__ uint32_t header_bytes(const HeaderCodes &h) {
+    return 4 + h.fn_bytes + h.bextra_bits / 8 + h.rextra_bits / 8 + 1;
+}
+
+__global__ void __launch_bounds__(1024) k_layout(Params p, PackParams q) {
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < p.n_frames; base += 1024) {
+        const uint32_t f = base + tid;
+        uint64_t size = 0;
+        if (f < p.n_frames) {
+            const flacgpu_frame_plan fp = p.frame_plan[f];
+            HeaderCodes h = header_codes(fp.block_size, q.sample_rate, q.first_frame_number + f);
+            size = header_bytes(h) + ((uint64_t)fp.body_bits + 7) / 8 + 2;
+        }
+        // inclusive scan inside the wave, then across the 16 waves
+        uint64_t v = size;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint64_t t = __shfl_up(v, off, 64);
+            if ((tid & 63) >= (uint32_t)off) v += t;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
+        __syncthreads();
+        uint64_t prefix = carry;
+        for (uint32_t w = 0; w < (tid >> 6); w++) prefix += wave_tot[w];
+        if (f < p.n_frames) q.frame_off[f] = prefix + v - size;
+        __syncthreads();
+        if (tid == 1023) carry = prefix + v;
+        __syncthreads();
+    }
+    if (tid == 0) q.frame_off[p.n_frames] = carry;
+}
+
+// zero the part of the output buffer the frames will occupy (16 bytes per lane)
+__global__ void __launch_bounds__(WG) k_zero(PackParams q, uint32_t n_frames) {
+    const uint64_t total = q.frame_off[n_frames];
+    const uint64_t n16 = (total + 15) / 16 + 1;
+    uint4 *o = reinterpret_cast<uint4 *>(q.out_words);
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * WG)
+        o[i] = make_uint4(0, 0, 0, 0);
+}
+
+// OR a field of nbits (<= 32) at bit position pos of an MSB-first bit string held in LDS words
+__device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, uint32_t nbits) {
+    if (nbits == 0) return;
+    if (nbits < 32) v &= (1u << nbits) - 1u;
+    const uint32_t w = pos >> 5, off = pos & 31;
+    if (off + nbits <= 32) {
+        atomicOr(&sb[w], v << (32 - off - nbits));
+    } else {
+        const uint32_t lo = off + nbits - 32;  // bits spilling into the next word
+        atomicOr(&sb[w], v >> lo);
+        atomicOr(&sb[w + 1], v << (32 - lo));
+    }
+}
+
+__global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint8_t hdr[16];
+    uint32_t frame, ch;
+    map_block(blockIdx.x, p.channels, p.n_frames, frame, ch);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = frame_len(p, frame);
+    const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
+    const uint32_t type = sp->type, order = sp->order, wasted = sp->wasted, bps = sp->bps;
+    const uint32_t sub_bits = sp->bits;
+
+    // position of this subframe inside the frame
+    const uint64_t fn = q.first_frame_number + frame;
+    const HeaderCodes hc = header_codes(n, q.sample_rate, fn);
+    const uint32_t hbytes = header_bytes(hc);
+    uint32_t start_bit = hbytes * 8;
+    for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
+    const uint32_t prefix_bits = ch == 0 ? hbytes * 8 : 0;  // subframe 0 also carries the header
+    const uint32_t total_bits = prefix_bits + sub_bits;
+    const uint32_t nwords = (total_bits + 31) / 32 + 1;
+
+    int32_t *r = lds;                                             // [block_size]
+    uint32_t *sb = reinterpret_cast<uint32_t *>(lds + p.block_size);  // bit string
+    for (uint32_t i = tid; i < nwords; i += WG) sb[i] = 0;
+    const int32_t *row = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
+    const uint32_t nload = type == FLACGPU_SUB_CONSTANT ? 1u : n;
+    for (uint32_t i = tid; i < nload; i += WG) r[i] = row[i];
+    __syncthreads();
+
+    const uint32_t base = prefix_bits;  // bit where the subframe starts inside sb
+    if (tid == 0) {
+        if (ch == 0) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
+            const flacgpu_frame_plan fp = p.frame_plan[frame];
+            uint32_t k = 0;
+            hdr[k++] = 0xFF;
+            hdr[k++] = 0xF8;  // sync 0b111111111111100 + blocking strategy 0
+            hdr[k++] = (uint8_t)((hc.bcode << 4) | hc.rcode);
+            const uint32_t acode = fp.assignment == FLACGPU_ASSIGN_INDEPENDENT ? p.channels - 1 : fp.assignment;
+            const uint32_t pcode = p.bps == 8 ? 1 : p.bps == 12 ? 2 : p.bps == 16 ? 4 : p.bps == 20 ? 5
+                                 : p.bps == 24 ? 6 : p.bps == 32 ? 7 : 0;
+            hdr[k++] = (uint8_t)((acode << 4) | (pcode << 1));
+            if (hc.fn_bytes == 1) {
+                hdr[k++] = (uint8_t)fn;
+            } else {  // UTF-8-like frame number, stream.rs:1264-1325
+                const uint32_t nb = hc.fn_bytes;
+                const uint32_t lead = (0xFFu << (8 - nb)) & 0xFF;
+                hdr[k++] = (uint8_t)(lead | (uint32_t)(fn >> (6 * (nb - 1))));
+                for (int b = (int)nb - 2; b >= 0; b--) hdr[k++] = (uint8_t)(0x80 | ((fn >> (6 * b)) & 0x3F));
+            }
+            if (hc.bextra_bits == 8) hdr[k++] = (uint8_t)(n - 1);
+            else if (hc.bextra_bits == 16) { hdr[k++] = (uint8_t)((n - 1) >> 8); hdr[k++] = (uint8_t)(n - 1); }
+            if (hc.rextra_bits == 8) hdr[k++] = (uint8_t)hc.rextra;
+            else if (hc.rextra_bits == 16) { hdr[k++] = (uint8_t)(hc.rextra >> 8); hdr[k++] = (uint8_t)hc.rextra; }
+            uint32_t crc = 0;  // CRC-8, poly 0x07 (crc.rs:99-128)
+            for (uint32_t i = 0; i < k; i++) {
+                crc ^= hdr[i];
+                for (int b = 0; b < 8; b++) crc = (crc & 0x80) ? ((crc << 1) ^ 0x07) & 0xFF : (crc << 1) & 0xFF;
+            }
+            hdr[k++] = (uint8_t)crc;
+            for (uint32_t i = 0; i < k; i++) lds_put(sb, 8 * i, hdr[i], 8);
+        }
+        // SubframeHeader, stream.rs:1390-1413
+        const uint32_t tcode = type == FLACGPU_SUB_CONSTANT ? 0u : type == FLACGPU_SUB_VERBATIM ? 1u
+                             : type == FLACGPU_SUB_FIXED ? 8u + order : 31u + order;
+        lds_put(sb, base, tcode, 7);
+        if (wasted) {
+            lds_put(sb, base + 7, 1, 1);
+            lds_put(sb, base + 8 + (wasted - 1), 1, 1);  // wasted-1 zeros then a one
+        }
+        if (type == FLACGPU_SUB_CONSTANT) lds_put(sb, base + 8 + wasted, (uint32_t)r[0], bps);
+    }
+    const uint32_t body0 = base + 8 + wasted;
+    if (type == FLACGPU_SUB_VERBATIM) {
+        for (uint32_t i = tid; i < n; i += WG) lds_put(sb, body0 + i * bps, (uint32_t)r[i], bps);
+    } else if (type == FLACGPU_SUB_FIXED || type == FLACGPU_SUB_LPC) {
+        // warm-up, precision, shift, coefficients (encode.rs:3083-3085, 3118-3133)
+        if (tid < order) lds_put(sb, body0 + tid * bps, (uint32_t)r[tid], bps);
+        uint32_t pos = body0 + order * bps;
+        if (type == FLACGPU_SUB_LPC) {
+            const uint32_t prec = sp->precision;
+            if (tid == 32) {
+                lds_put(sb, pos, prec - 1, 4);
+                lds_put(sb, pos + 4, sp->shift, 5);
+            }
+            if (tid >= 64 && tid < 64 + order) lds_put(sb, pos + 9 + (tid - 64) * prec, (uint32_t)sp->coeffs[tid - 64], prec);
+            pos += 9 + order * prec;
+        }
+        // residual block (encode.rs:3944-3961, 3898-3907)
+        const uint32_t method = sp->coding_method, hb = method ? 5u : 4u, esc_code = method ? 31u : 15u;
+        if (tid == 96) {
+            lds_put(sb, pos, method, 2);
+            lds_put(sb, pos + 2, sp->partition_order, 4);
+        }
+        pos += 6;
+        const uint32_t np = sp->n_partitions, plen = sp->part_len;
+        const uint32_t first_j = plen ? n / plen - np : 0;  // chunks lying inside the warm-up
+        const uint32_t ept = (n + WG - 1) / WG;
+        const uint32_t lo = tid * ept > order ? tid * ept : order;
+        const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
+        // pass 1: code lengths of this lane's residuals (+ partition headers)
+        uint32_t mybits = 0;
+        if (lo < hi) {
+            uint32_t pj = lo / plen;                 // partition (block-aligned index)
+            uint32_t bound = (pj + 1) * plen;
+            uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
+            const uint32_t pstart0 = pj * plen > order ? pj * plen : order;
+            if (lo == pstart0) mybits += hb + (k == 0xFF ? 5u : 0u);
+            for (uint32_t i = lo; i < hi; i++) {
+                if (i == bound) {
+                    pj++;
+                    bound += plen;
+                    k = sp->rice[pj - first_j];
+                    eb = sp->escape_bits[pj - first_j];
+                    mybits += hb + (k == 0xFF ? 5u : 0u);
+                }
+                mybits += (k != 0xFF) ? (zigzag(r[i]) >> k) + 1u + k : eb;
+            }
+        }
+        // exclusive scan of mybits over the workgroup
+        uint32_t v = mybits;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(v, off, 64);
+            if ((tid & 63) >= (uint32_t)off) v += t;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
+        __syncthreads();
+        uint32_t mypos = pos + v - mybits;
+        for (uint32_t w = 0; w < (tid >> 6); w++) mypos += wave_tot[w];
+        // pass 2: emit
+        if (lo < hi) {
+            uint32_t pj = lo / plen;
+            uint32_t bound = (pj + 1) * plen;
+            uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
+            const uint32_t pstart0 = pj * plen > order ? pj * plen : order;
+            if (lo == pstart0) {
+                if (k != 0xFF) { lds_put(sb, mypos, k, hb); mypos += hb; }
+                else { lds_put(sb, mypos, esc_code, hb); lds_put(sb, mypos + hb, eb, 5); mypos += hb + 5; }
+            }
+            for (uint32_t i = lo; i < hi; i++) {
+                if (i == bound) {
+                    pj++;
+                    bound += plen;
+                    k = sp->rice[pj - first_j];
+                    eb = sp->escape_bits[pj - first_j];
+                    if (k != 0xFF) { lds_put(sb, mypos, k, hb); mypos += hb; }
+                    else { lds_put(sb, mypos, esc_code, hb); lds_put(sb, mypos + hb, eb, 5); mypos += hb + 5; }
+                }
+                if (k != 0xFF) {
+                    const uint32_t u = zigzag(r[i]);
+                    const uint32_t qn = u >> k;
+                    mypos += qn;  // unary zeros (buffer is pre-zeroed)
+                    lds_put(sb, mypos, (1u << k) | (u & ((1u << k) - 1u)), k + 1);
+                    mypos += k + 1;
+                } else if (eb) {
+                    lds_put(sb, mypos, (uint32_t)r[i], eb);
+                    mypos += eb;
+                }
+            }
+        }
+        if (n == order && tid == 0) {  // no residuals at all: lone partition header
+            const uint32_t k = sp->rice[0], eb = sp->escape_bits[0];
+            if (k != 0xFF) lds_put(sb, pos, k, hb);
+            else { lds_put(sb, pos, esc_code, hb); lds_put(sb, pos + hb, eb, 5); }
+        }
+    }
+    __syncthreads();
+    // copy out: absolute bit position of sb[0] in the output stream
+    const uint64_t abs_bit = q.frame_off[frame] * 8ull + (ch == 0 ? 0u : start_bit);
+    const uint64_t w0 = abs_bit >> 5;
+    const uint32_t s = (uint32_t)(abs_bit & 31);
+    const uint32_t nout = (s + total_bits + 31) / 32;
+    for (uint32_t j = tid; j < nout; j += WG) {
+        uint32_t val;
+        if (s == 0) val = sb[j];
+        else val = (j ? (sb[j - 1] << (32 - s)) : 0u) | (sb[j] >> s);
+        const uint32_t be = __builtin_bswap32(val);
+        if (j == 0 || j + 1 == nout) atomicOr(&q.out_words[w0 + j], be);
+        else q.out_words[w0 + j] = be;
+    }
+}
+
+// CRC-16 (poly 0x8005, MSB first, init 0; crc.rs:142-188) of every packed frame
+__device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b) {  // a*b mod P over GF(2)
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000) ? ((r << 1) ^ 0x8005) & 0xFFFF : (r << 1) & 0xFFFF;
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+__global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
+    __shared__ uint16_t table[256];
+    __shared__ uint32_t part[WG];
+    const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+    {
+        uint32_t c = tid << 8;
+        for (int b = 0; b < 8; b++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
+        table[tid] = (uint16_t)c;
+    }
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(q.out_words);
+    const uint64_t begin = q.frame_off[frame];
+    const uint32_t len = (uint32_t)(q.frame_off[frame + 1] - begin) - 2;  // all but the CRC itself
+    const uint32_t m = (len + WG - 1) / WG;                               // slice length
+    __syncthreads();
+    // slices are aligned to the END of the frame; a short first slice acts as if it were
+    // left-padded with zero bytes, which leave a zero CRC state unchanged
+    const int64_t hi = (int64_t)len - (int64_t)(WG - 1 - tid) * m;
+    const int64_t lo = hi - m;
+    uint32_t crc = 0;
+    for (int64_t i = lo < 0 ? 0 : lo; i < hi; i++)
+        crc = (table[(crc >> 8) ^ bytes[begin + i]] ^ (crc << 8)) & 0xFFFF;
+    part[tid] = crc;
+    // x^(8m) mod P by square-and-multiply
+    uint32_t xp = 1, basep = 0x100 % 0x18005;  // x^8
+    {
+        uint32_t e = m, b2 = 0x100;
+        // reduce x^8 (degree 8 < 16: already reduced)
+        basep = b2;
+        while (e) {
+            if (e & 1) xp = gf_mulmod(xp, basep);
+            basep = gf_mulmod(basep, basep);
+            e >>= 1;
+        }
+    }
+    __syncthreads();
+    // tree: at each level the right operand spans `span` slices => shift the left by x^(8*m*span)
+    uint32_t shift = xp;
+    for (uint32_t span = 1; span < WG; span <<= 1) {
+        if ((tid & (2 * span - 1)) == 0) part[tid] = gf_mulmod(part[tid], shift) ^ part[tid + span];
+        shift = gf_mulmod(shift, shift);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
+        ob[begin + len] = (uint8_t)(part[0] >> 8);
+        ob[begin + len + 1] = (uint8_t)part[0];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
 const char *const kKernelNames[FLACGPU_N_KERNELS] = {
     "k_deinterleave", "k_stereo_stats", "k_fixed", "k_autocorr", "k_lpc",
-    "k_fir",          "k_decide",       "k_emit",  "(unused)",   "(unused)"};
+    "k_fir",          "k_decide",       "k_emit",  "k_layout",   "k_pack",
+    "k_crc",          "(unused)"};
 
 }  // namespace
 
@@ -1148,6 +1522,11 @@ struct flacgpu_ctx {
     FrameInfo *d_finfo = nullptr;
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
+    uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
+    uint64_t *d_frame_off = nullptr;
+    uint64_t packed_cap = 0;        // bytes
+    bool packed_valid = false;
+    Params last_params;
     uint32_t window_last_len = 0;
     hipStream_t own_stream = nullptr;
     // last call
@@ -1227,6 +1606,12 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
     HIP_TRY(hipMemcpyAsync(dst, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // `w` is a local
     return 0;
+}
+
+// dynamic LDS of k_pack: the residual row + the subframe's bit string (a chosen subframe is
+// never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
+size_t pack_lds_bytes(uint32_t block_size) {
+    return (size_t)block_size * 4 + ((size_t)block_size * 33 / 32 + 32) * 4;
 }
 
 template <int H>
@@ -1311,6 +1696,10 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     ALLOC(c->d_finfo, F);
     ALLOC(c->d_fplan, F);
     ALLOC(c->d_stats, 4);
+    // worst case: every subframe VERBATIM at 32 bits + headers
+    c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
+    ALLOC(c->d_packed, c->packed_cap / 4 + 8);
+    ALLOC(c->d_frame_off, F + 1);
 #undef ALLOC
     HIP_TRY(hipStreamCreate(&c->own_stream));
     HIP_TRY(hipMemsetAsync(c->d_planar, 0, sizeof(int32_t) * (F * C * c->ldb + slack), c->own_stream));
@@ -1325,6 +1714,8 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, dyn / 2));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(pack_lds_bytes((uint32_t)B))));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
     *out = c;
@@ -1337,6 +1728,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off);
     if (c->ev_ok) for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1457,6 +1849,8 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     HIP_TRY(hipGetLastError());
     c->last_frames = n_frames;
     c->last_len = last_len;
+    c->last_params = p;
+    c->packed_valid = false;
     if (c->timing) {
         HIP_TRY(hipStreamSynchronize(st));
         for (auto &m : c->last_ms) m = 0.f;
@@ -1503,6 +1897,87 @@ int flacgpu_analyze(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32_t n_f
     return flacgpu_fetch(c, plans, subs, residuals);
 }
 
+
+int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate,
+                        void *stream) {
+    if (!c || c->last_frames == 0) {
+        g_last_error = "flacgpu_pack_device: no analysed batch";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    const Params &p = c->last_params;
+    PackParams q;
+    q.first_frame_number = first_frame_number;
+    q.sample_rate = sample_rate;
+    q.out_words = c->d_packed;
+    q.frame_off = c->d_frame_off;
+    q.cap_bytes = c->packed_cap;
+    hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
+    if (c->timing) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
+    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
+    if (c->timing) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_pack, dim3(p.n_frames * p.channels), dim3(WG), pack_lds_bytes(p.block_size),
+                       st, p, q);
+    if (c->timing) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_crc, dim3(p.n_frames), dim3(WG), 0, st, p, q);
+    if (c->timing) (void)hipEventRecord(ev[3], st);
+    HIP_TRY(hipGetLastError());
+    c->packed_valid = true;
+    if (c->timing) {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < 3; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            c->last_ms[8 + i] = ms;
+        }
+    }
+    return FLACGPU_OK;
+}
+
+int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *offsets,
+                         uint64_t *total) {
+    if (!c || !c->packed_valid) {
+        g_last_error = "flacgpu_fetch_frames: nothing packed";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const size_t F = c->last_frames;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint64_t> off;
+    uint64_t *offp = offsets;
+    if (!offp) {
+        off.resize(F + 1);
+        offp = off.data();
+    }
+    HIP_TRY(hipMemcpy(offp, c->d_frame_off, sizeof(uint64_t) * (F + 1), hipMemcpyDeviceToHost));
+    const uint64_t bytes = offp[F];
+    if (total) *total = bytes;
+    if (!out || cap < bytes) {
+        g_last_error = "output buffer too small";
+        return FLACGPU_ERR_BUFFER_TOO_SMALL;
+    }
+    HIP_TRY(hipMemcpy(out, c->d_packed, bytes, hipMemcpyDeviceToHost));
+    return FLACGPU_OK;
+}
+
+int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32_t n_frames,
+                          uint32_t last_len, uint64_t first_frame_number, uint32_t sample_rate,
+                          uint8_t *out, size_t cap, uint64_t *offsets, uint64_t *total) {
+    if (!c || !pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size) {
+        g_last_error = "invalid encode arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const size_t B = c->opts.block_size, C = c->channels;
+    const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
+    HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, c->own_stream));
+    int rc = flacgpu_analyze_device(c, c->d_in, layout, n_frames, last_len, c->own_stream);
+    if (rc) return rc;
+    rc = flacgpu_pack_device(c, first_frame_number, sample_rate, c->own_stream);
+    if (rc) return rc;
+    return flacgpu_fetch_frames(c, out, cap, offsets, total);
+}
+
 int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     if (!c || !out) return FLACGPU_ERR_INVALID_ARG;
     uint32_t s[4];
@@ -1522,6 +1997,8 @@ void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     case 1: return c->d_out;
     case 2: return c->d_resid;
     case 3: return c->d_planar;
+    case 4: return c->d_packed;
+    case 5: return c->d_frame_off;
     default: return nullptr;
     }
 }

@@ -78,6 +78,42 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_fetch")
         return plans, subs, res
 
+    def pack_device(self, first_frame_number, sample_rate, stream=None):
+        """Device-side frame assembly of the last analysed batch (bytes stay in HBM)."""
+        rc = _lib.lib().flacgpu_pack_device(self._h, first_frame_number, sample_rate,
+                                            C.c_void_p(stream or 0))
+        if rc:
+            raise GpuError(rc, "flacgpu_pack_device")
+
+    def fetch_frames(self, n_frames):
+        """Returns (bytes, offsets[n_frames+1]) of the frames packed on the device."""
+        off = (C.c_uint64 * (n_frames + 1))()
+        total = C.c_uint64(0)
+        L = _lib.lib()
+        rc = L.flacgpu_fetch_frames(self._h, None, 0, off, C.byref(total))
+        if rc not in (0, -5):
+            raise GpuError(rc, "flacgpu_fetch_frames")
+        buf = np.empty(total.value, dtype=np.uint8)
+        rc = L.flacgpu_fetch_frames(self._h, buf.ctypes.data, buf.size, off, C.byref(total))
+        if rc:
+            raise GpuError(rc, "flacgpu_fetch_frames")
+        return buf.tobytes(), list(off)
+
+    def encode_frames(self, pcm, n_frames, last_frame_len, first_frame_number, sample_rate,
+                      layout=LAYOUT_INTERLEAVED):
+        """analyze + pack + fetch on host PCM; returns (bytes, offsets)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        cap = pcm.size * 4 + n_frames * 128 + 1024
+        buf = np.empty(cap, dtype=np.uint8)
+        off = (C.c_uint64 * (n_frames + 1))()
+        total = C.c_uint64(0)
+        rc = _lib.lib().flacgpu_encode_frames(
+            self._h, pcm.ctypes.data_as(C.POINTER(C.c_int32)), layout, n_frames, last_frame_len,
+            first_frame_number, sample_rate, buf.ctypes.data, cap, off, C.byref(total))
+        if rc:
+            raise GpuError(rc, "flacgpu_encode_frames")
+        return buf[: total.value].tobytes(), list(off)
+
     def stats(self):
         s = GpuStats()
         rc = _lib.lib().flacgpu_get_stats(self._h, C.byref(s))
@@ -94,3 +130,22 @@ class GpuAnalyzer:
         L = _lib.lib()
         return {L.flacgpu_kernel_name(i).decode(): float(arr[i]) for i in range(_lib.N_KERNELS)
                 if arr[i] > 0}
+
+
+def host_pack_frames(sample_rate, bits_per_sample, channels, first_frame_number, n_frames,
+                     row_stride, plans, subs, rows, threads=1):
+    """Host bit-packing of an analysed batch (flacenc_pack_frames); returns (bytes, offsets)."""
+    L = _lib.lib()
+    off = (C.c_uint64 * (n_frames + 1))()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    args = (sample_rate, bits_per_sample, channels, first_frame_number, n_frames, row_stride,
+            C.cast(plans, C.c_void_p), C.cast(subs, C.c_void_p),
+            rows.ctypes.data_as(C.POINTER(C.c_int32)), threads)
+    rc = L.flacenc_pack_frames(*args, None, 0, off)
+    if rc not in (0, -140):
+        raise RuntimeError(f"flacenc_pack_frames: {rc}")
+    buf = np.empty(off[n_frames], dtype=np.uint8)
+    rc = L.flacenc_pack_frames(*args, buf.ctypes.data, buf.size, off)
+    if rc:
+        raise RuntimeError(f"flacenc_pack_frames: {rc}")
+    return buf.tobytes(), list(off)

@@ -159,12 +159,36 @@ int flacgpu_fetch(flacgpu_ctx *ctx, flacgpu_frame_plan *plans, flacgpu_subframe_
 int flacgpu_get_stats(flacgpu_ctx *ctx, flacgpu_stats *out);
 
 /* Device pointers of the last analysis (for callers that chain further device work):
- * which: 0 frame plans, 1 subframe plans, 2 residuals, 3 planar pcm. */
+ * which: 0 frame plans, 1 subframe plans, 2 residuals, 3 planar pcm, 4 packed frame bytes,
+ * 5 frame byte offsets (uint64[n_frames + 1]). */
 void *flacgpu_device_buffer(flacgpu_ctx *ctx, int which);
+
+/* ---- device-side frame assembly ---------------------------------
+ * Replaces, for the frames of the last flacgpu_analyze_device call, the host half of
+ * encode_frame (encode.rs:2284-2294 header, :2332-2333 playback, :2408-2409 align + CRC-16)
+ * and write_partitions / Partition::to_writer (encode.rs:3834-3907): frame header + CRC-8,
+ * subframe headers, warm-up, LPC parameters, Rice/escaped residual codes (bit offsets by
+ * prefix scan), byte alignment, CRC-16 -- producing the exact bytes `Encoder::encode` would
+ * hand to its writer.  Frame f carries frame number first_frame_number + f.
+ * Asynchronous; results stay in HBM until flacgpu_fetch_frames. */
+int flacgpu_pack_device(flacgpu_ctx *ctx, uint64_t first_frame_number, uint32_t sample_rate,
+                        void *stream);
+/* Copies the packed frames of the last flacgpu_pack_device to the host.  offsets (may be NULL)
+ * receives n_frames + 1 byte offsets into `out`; *total (may be NULL) the byte count.  When
+ * `out` is NULL or cap is too small only offsets/total are filled and
+ * FLACGPU_ERR_BUFFER_TOO_SMALL is returned. */
+int flacgpu_fetch_frames(flacgpu_ctx *ctx, uint8_t *out, size_t cap, uint64_t *offsets,
+                         uint64_t *total);
+/* analyze + pack + fetch in one synchronous call on host PCM: the whole of the reference's
+ * `Encoder::encode` loop for a batch of blocks, minus stream bookkeeping. */
+int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n_frames,
+                          uint32_t last_frame_len, uint64_t first_frame_number,
+                          uint32_t sample_rate, uint8_t *out, size_t cap, uint64_t *offsets,
+                          uint64_t *total);
 
 /* Duration in milliseconds of each kernel of the last analyze call, measured with HIP events
  * on the launch stream (names via flacgpu_kernel_name).  Requires flacgpu_set_timing(ctx, 1). */
-#define FLACGPU_N_KERNELS 10
+#define FLACGPU_N_KERNELS 12
 int flacgpu_set_timing(flacgpu_ctx *ctx, int enable);
 int flacgpu_get_kernel_ms(flacgpu_ctx *ctx, float ms[FLACGPU_N_KERNELS]);
 const char *flacgpu_kernel_name(int index);

@@ -1,0 +1,95 @@
+"""Device-side frame assembly (k_layout / k_pack / k_crc) against (a) the host bit-packer of
+the product and (b) the oracle's frame bytes -- all three must agree byte for byte."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import generate_sine_2, read_raw, synth, synth_fast
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(pcm, channels, bps, block_size=4096, max_po=6, max_lpc=12, mid_side=True,
+             exhaustive=True, rate=48000, first_frame=0):
+    from flac_codec_amd.gpu import GpuAnalyzer, host_pack_frames
+
+    frames = planar_frames(pcm, channels, block_size)
+    n_frames, last = len(frames), frames[-1].shape[1]
+    an = GpuAnalyzer(block_size, max_po, max_lpc, mid_side, exhaustive, 2, 0.5, bps, channels,
+                     max_frames=n_frames)
+    used = pcm[: ((n_frames - 1) * block_size + last) * channels]
+    plans, subs, res = an.analyze(used, n_frames, last)
+    an.pack_device(first_frame, rate)
+    dev_bytes, dev_off = an.fetch_frames(n_frames)
+    host_bytes, host_off = host_pack_frames(rate, bps, channels, first_frame, n_frames, block_size,
+                                            plans, subs, res, threads=2)
+    assert dev_off == host_off
+    oopts = orc_options_for(block_size, max_po, max_lpc, mid_side, exhaustive)
+    for f, planar in enumerate(frames):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first_frame + f)
+        assert rc == 0
+        d = dev_bytes[dev_off[f]:dev_off[f + 1]]
+        h = host_bytes[host_off[f]:host_off[f + 1]]
+        assert h == fb, f"frame {f}: host packer differs from oracle"
+        if d != fb:
+            diff = next(i for i in range(min(len(d), len(fb))) if d[i] != fb[i]) if len(d) == len(fb) else -1
+            raise AssertionError(f"frame {f}: device packer differs from oracle at byte {diff} "
+                                 f"(len {len(d)} vs {len(fb)})")
+    # one-call variant
+    b2, o2 = an.encode_frames(used, n_frames, last, first_frame, rate)
+    assert b2 == dev_bytes and o2 == dev_off
+    an.close()
+
+
+def test_headline_shape():
+    run_case(synth_fast(200, 2, 24, 4096 * 20 + 333), 2, 24)
+
+
+def test_16bit_default_and_fixed():
+    run_case(synth_fast(201, 2, 16, 4096 * 6), 2, 16, max_po=5, max_lpc=8, rate=44100)
+    run_case(synth_fast(202, 2, 16, 4096 * 6), 2, 16, max_po=5, max_lpc=0, rate=44100)
+
+
+def test_multichannel_and_mono():
+    run_case(synth_fast(203, 8, 24, 4096 * 3), 8, 24, rate=192000)
+    run_case(synth_fast(204, 1, 16, 4096 * 3 + 10), 1, 16)
+    run_case(synth_fast(205, 3, 20, 4096 * 2), 3, 20, rate=32000)
+
+
+def test_order32_and_uncommon_rates():
+    run_case(synth_fast(206, 2, 24, 4096 * 3), 2, 24, max_lpc=32, rate=96000)
+    for rate in (11025, 12345, 100000, 65530, 700001, 384000):
+        run_case(synth_fast(207, 2, 16, 1000 * 2), 2, 16, block_size=1000, rate=rate)
+
+
+def test_frame_number_lengths():
+    pcm = synth_fast(208, 2, 16, 576 * 4)
+    for first in (0, 126, 0x7FE, 0xFFFE, 0x1FFFFE, 0x3FFFFFE, 0x7FFFFFFE, 0xFFFFFFFF0):
+        run_case(pcm, 2, 16, block_size=576, first_frame=first)
+
+
+def test_verbatim_constant_wasted_escape():
+    rng = np.random.Generator(np.random.PCG64(209))
+    run_case(rng.integers(-(1 << 23), 1 << 23, size=4096 * 4, dtype=np.int64).astype(np.int32), 2, 24)
+    run_case(np.zeros(4096 * 4, dtype=np.int32), 2, 16)
+    run_case(read_raw("wasted-bits.raw", 16), 1, 16)
+    run_case(rng.integers(-(1 << 31), 1 << 31, size=4096 * 4, dtype=np.int64).astype(np.int32), 2, 32)
+    # mostly silent with rare huge spikes: long unary runs / escaped partitions
+    x = np.zeros(4096 * 4, dtype=np.int32)
+    x[::997] = (1 << 22)
+    x[5::1013] = -(1 << 22)
+    run_case(x, 2, 24)
+    run_case(x, 1, 24, max_lpc=0)
+
+
+def test_block_sizes_and_short_tail():
+    for bs in (16, 33, 192, 1152, 4608, 16384):
+        run_case(synth_fast(210 + bs, 2, 16, bs * 2 + bs // 3), 2, 16, block_size=bs)
+    run_case(read_raw("noise32.raw", 8), 1, 8, block_size=17, max_lpc=16)
+
+
+def test_fast_preset_and_sines():
+    run_case(synth_fast(220, 2, 16, 1152 * 5), 2, 16, block_size=1152, max_po=3, max_lpc=0,
+             mid_side=False, exhaustive=False)
+    run_case(generate_sine_2(8388607.0, 48000.0, 4096 * 3, 441.0, 0.0, 4410.0, 0.1, 1.3), 2, 24)
