@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- FLAC encode hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s encode at "level 8" (= reference Options::best():
+block 4096, LPC order <= 12, partition order <= 6, mid-side, exhaustive channel
+correlation), 48 kHz / 24-bit stereo, output bit-exact vs the reference restatement.
+
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already
+resident in HBM (interleaved int32, the layout FlacSampleWriter::write receives):
+de-interleave -> fixed/LPC analysis -> channel-assignment decision -> residuals -> frame
+assembly (headers, Rice bit-packing, CRC-8/16) -> finished FLAC frame bytes in HBM.
+Stream bookkeeping that the reference keeps per stream on the host (MD5 of the PCM,
+metadata rewrite) is outside the step; DESIGN.md states its cost and the PCIe-inclusive rate.
+
+Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torchrun)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+BLOCK = 4096
+CHANNELS = 2
+BPS = 24
+RATE = 48000
+MAX_LPC = 12
+MAX_PO = 6
+FRAMES = 8192          # 8192 blocks x 4096
+DISTINCT = 512         # distinct synthetic frames, tiled to FRAMES
+
+
+def make_pcm(seed, frames):
+    from _pcm import synth_fast
+
+    base = synth_fast(seed, CHANNELS, BPS, BLOCK * min(DISTINCT, frames))
+    reps = (frames + DISTINCT - 1) // DISTINCT
+    return np.tile(base, reps)[: frames * BLOCK * CHANNELS]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES, help="FLAC frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist = dist_mod
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+    from flac_codec_amd.parallel import gather_shard_counters
+
+    F = args.frames
+    pcm = make_pcm(1000 + rank, F)                 # every rank encodes its own frame range
+    d_pcm = torch.from_numpy(pcm).cuda()
+    an = GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
+                     device=local_rank)
+    first_frame = rank * F                          # contiguous frame ranges per GPU (8(e))
+
+    def step():
+        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+        an.pack_device(first_frame, RATE)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # per-shard counters (frames, bytes, min/max frame size) gathered over RCCL: the only
+    # cross-GPU exchange of the path (seek-table offsets / STREAMINFO)
+    counters = gather_shard_counters(an, F, dist)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = F * BLOCK * CHANNELS * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        # ---- parity precondition on this very batch: first frames byte-identical to the oracle
+        import _oracle as orc
+        from _compare import orc_options_for
+
+        data, off = an.fetch_frames(F)
+        oopts = orc_options_for(BLOCK, MAX_PO, MAX_LPC, True, True)
+        check = 16
+        for f in range(check):
+            planar = np.ascontiguousarray(
+                pcm[f * BLOCK * CHANNELS:(f + 1) * BLOCK * CHANNELS].reshape(BLOCK, CHANNELS).T)
+            rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
+            assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
+        compressed_bytes = off[F]
+
+        # ---- per-kernel durations (HIP events on the launch stream), one extra timed pass
+        an.set_timing(True)
+        reps = 5
+        acc = {}
+        for _ in range(reps):
+            an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+            ms_a = an.kernel_ms()
+            an.pack_device(first_frame, RATE)
+            ms_b = an.kernel_ms()
+            for k, v in {**ms_a, **ms_b}.items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        an.set_timing(False)
+        n_cand = 4 * F                      # L, R, M, S per stereo frame
+        cand_samples = n_cand * BLOCK
+        # algorithmic bytes / flops per launch (DESIGN.md "Kernels")
+        alg = {
+            "k_deinterleave": ("hbm", 8.0 * F * BLOCK * CHANNELS),
+            "k_fixed": ("hbm", 8.0 * cand_samples),
+            "k_autocorr": ("f64", 2.0 * BLOCK * (MAX_LPC + 1) * n_cand),
+            "k_fir": ("hbm", 8.0 * cand_samples),
+            "k_emit": ("hbm", 8.0 * F * BLOCK * CHANNELS),
+            "k_pack": ("hbm", 4.0 * F * BLOCK * CHANNELS + compressed_bytes),
+            "k_crc": ("hbm", float(compressed_bytes)),
+        }
+        kernels = {}
+        for k, ms in acc.items():
+            entry = {"ms": round(ms, 4)}
+            if k in alg and ms > 0:
+                kind, amount = alg[k]
+                if kind == "hbm":
+                    entry["GB/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+                else:
+                    entry["GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+            kernels[k] = entry
+        hbm_kernels = {k: v for k, v in kernels.items() if "GB/s" in v}
+        dom = max(hbm_kernels, key=lambda k: hbm_kernels[k]["ms"])
+        achieved = hbm_kernels[dom]["GB/s"]
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                    "avg_launch_ms": hbm_kernels[dom]["ms"]}
+
+        # ---- CPU baseline: the oracle (C restatement of the reference, NOT the Rust binary),
+        # timed on this box's host cores over the same workload
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_frames = min(F, 4096)
+            sample = pcm[: cpu_frames * BLOCK * CHANNELS]
+            oo = orc.options("best")
+            t1 = time.perf_counter()
+            rc, ref, _ = orc.encode_stream(oo, RATE, BPS, CHANNELS, sample, total_known=True, threads=1)
+            dt1 = time.perf_counter() - t1
+            assert rc == 0
+            ncores = os.cpu_count() or 1
+            t2 = time.perf_counter()
+            rc, ref2, _ = orc.encode_stream(oo, RATE, BPS, CHANNELS, sample, total_known=True,
+                                            threads=ncores)
+            dtn = time.perf_counter() - t2
+            assert ref == ref2
+            cpu = {"value": round(sample.size / dt1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                   "kind": "port",
+                   "sample": f"first {cpu_frames} frames of the bench batch, full encode to an "
+                             f"in-memory .flac (MD5 + analysis + bit-pack + CRC), 1 thread",
+                   "all_cores_frame_parallel": {"value": round(sample.size / dtn / 1e6, 3),
+                                                "cores": ncores,
+                                                "note": "not something the reference does"}}
+        out = {
+            "metric": "Msamples/s encode at level 8, 48kHz/24-bit stereo; bit-exact vs reference",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i32/i64 (+f64 LPC analysis)",
+            "data": "synthetic",
+            "config": {"workload": "48 kHz/24-bit stereo, blocksize 4096, level 8 (Options::best: "
+                                   "LPC order 12, partition order 6, mid-side, exhaustive), "
+                                   f"{F} frames per GPU per step, PCM resident in HBM, frame bytes "
+                                   "produced in HBM",
+                       "frames_per_gpu": F, "parallelism": f"frame ranges x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+            "compression_ratio": round(compressed_bytes / (F * BLOCK * CHANNELS * 3), 4),
+            "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
+            "parity_checked_frames": check,
+            "shard_counters": counters,
+        }
+    an.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -345,9 +345,11 @@ struct flacenc_writer {
     // :2408-2436), `n_frames` blocks of block_size, the last one `last_len` long.
     int encode_blocks(const int32_t *interleaved, uint32_t n_frames, uint32_t last_len) {
         const uint32_t B = o.block_size, C = si.channels;
-        plans.resize(n_frames);
-        subs.resize(static_cast<size_t>(n_frames) * C);
-        rows.resize(static_cast<size_t>(n_frames) * C * B);
+        if (o.host_pack) {
+            plans.resize(n_frames);
+            subs.resize(static_cast<size_t>(n_frames) * C);
+            rows.resize(static_cast<size_t>(n_frames) * C * B);
+        }
         // ExcessiveTotalSamples is raised BEFORE the offending frame is encoded (:2006-2011)
         uint32_t usable = n_frames;
         int deferred = 0;
@@ -364,20 +366,34 @@ struct flacenc_writer {
         }
         if (usable) {
             const uint32_t ll = (usable == n_frames) ? last_len : B;
-            double t0 = now_ms();
-            int rc = flacgpu_analyze(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
-                                     plans.data(), subs.data(), rows.data());
-            stats.gpu_ms += now_ms() - t0;
-            if (rc) return map_gpu_error(rc);
             if (frame_number + usable - 1 > kMaxFrameNumber) return FLACENC_ERR_EXCESSIVE_FRAME_NUMBER;
-            t0 = now_ms();
             PackedBatch pb;
-            if (int e = pack_batch(si.sample_rate, si.bps, C, frame_number, usable, B, plans.data(),
-                                   subs.data(), rows.data(), pack_threads, pb))
-                return e;
-            stats.pack_ms += now_ms() - t0;
+            double t0 = now_ms();
+            if (o.host_pack) {
+                int rc = flacgpu_analyze(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
+                                         plans.data(), subs.data(), rows.data());
+                stats.gpu_ms += now_ms() - t0;
+                if (rc) return map_gpu_error(rc);
+                t0 = now_ms();
+                if (int e = pack_batch(si.sample_rate, si.bps, C, frame_number, usable, B, plans.data(),
+                                       subs.data(), rows.data(), pack_threads, pb))
+                    return e;
+                stats.pack_ms += now_ms() - t0;
+            } else {
+                // frames assembled on the device: only the finished bytes cross PCIe
+                std::vector<uint64_t> off(usable + 1);
+                pb.bytes.resize((static_cast<size_t>(usable - 1) * B + ll) * C * 4 + usable * 128 + 1024);
+                uint64_t total = 0;
+                int rc = flacgpu_encode_frames(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
+                                               frame_number, si.sample_rate, pb.bytes.data(),
+                                               pb.bytes.size(), off.data(), &total);
+                stats.gpu_ms += now_ms() - t0;
+                if (rc) return map_gpu_error(rc);
+                pb.bytes.resize(total);
+                pb.offsets.assign(off.begin(), off.end());
+            }
             for (uint32_t f = 0; f < usable; f++) {
-                const uint32_t n = plans[f].block_size;
+                const uint32_t n = (f + 1 == usable) ? ll : B;
                 seekpoints.push_back({samples_written, byte_count + pb.offsets[f], static_cast<uint16_t>(n), true});
                 samples_written += n;
                 const uint32_t size = static_cast<uint32_t>(pb.offsets[f + 1] - pb.offsets[f]);

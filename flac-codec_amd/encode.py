@@ -87,7 +87,7 @@ class _COptions(C.Structure):
         ("batch_frames", C.c_uint32),
         ("device", C.c_int32),
         ("pack_threads", C.c_uint32),
-        ("reserved1", C.c_uint32),
+        ("host_pack", C.c_uint32),
     ]
 
 
@@ -269,6 +269,11 @@ class Options:
 
     def pack_threads(self, n):
         self._c.pack_threads = n
+        return self
+
+    def host_pack(self, on=True):
+        """Keep Rice bit-packing + CRC on the host (default: assembled on the GPU)."""
+        self._c.host_pack = int(bool(on))
         return self
 
     def _open(self, path):  # Options::create, encode.rs:1660-1671

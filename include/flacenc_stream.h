@@ -79,7 +79,9 @@ typedef struct {
     uint32_t batch_frames;        /* FLAC frames analysed per GPU call; 0 = default (1024) */
     int32_t device;               /* HIP device ordinal, -1 = current */
     uint32_t pack_threads;        /* host bit-pack threads; 0 = default */
-    uint32_t reserved1;
+    uint32_t host_pack;           /* 0: frames are assembled on the GPU (k_layout/k_pack/k_crc);
+                                     1: Rice bit-packing + CRC stay on the host, as in the
+                                     north-star split (same bytes either way) */
 } flacenc_options;
 
 void flacenc_options_default(flacenc_options *o); /* Options::default(), encode.rs:1376-1408 */

@@ -50,11 +50,12 @@ def encode_samples(opts, rate, bps, ch, pcm, total_known=True, chunk=None, write
     return data
 
 
-def test_headline_config_stream():  # BASELINE config 3, small: L8, 48 kHz / 24-bit stereo
+@pytest.mark.parametrize("host_pack", [False, True])
+def test_headline_config_stream(host_pack):  # BASELINE config 3, small: L8, 48 kHz / 24-bit stereo
     from flac_codec_amd.encode import Options
 
     pcm = synth_fast(100, 2, 24, 4096 * 40 + 777)
-    opts = Options.best().batch_frames(16)
+    opts = Options.best().batch_frames(16).host_pack(host_pack)
     data = encode_samples(opts, 48000, 24, 2, pcm, chunk=10007)
     check_stream(data, pcm, 48000, 24, 2, opts, True)
 
@@ -100,7 +101,7 @@ def test_presets_channels(preset, ch, bps):  # tests/format.rs:1248-1384 shape
     pcm = synth_fast(103 + ch + bps, ch, min(bps, 24), 4096 * 3 + 100)
     if bps == 32:
         pcm = (pcm.astype(np.int64) << 8).astype(np.int32)
-    opts = getattr(Options, preset)().no_padding()
+    opts = getattr(Options, preset)().no_padding().host_pack(ch == 4)
     data = encode_samples(opts, 44100, bps, ch, pcm, chunk=4099 * ch)
     check_stream(data, pcm, 44100, bps, ch, opts, True)
 
