@@ -82,6 +82,7 @@ struct Params {
     uint32_t mid_side, exhaustive;
     uint32_t max_lpc_order, max_po, use_rice2;
     uint32_t n_frames, last_len;
+    uint32_t dbg;                                  // timing experiments only (FLACGPU_DEBUG)
     // buffers
     const int32_t *planar;
     const double *window_full, *window_last;
@@ -200,14 +201,16 @@ __device__ __forceinline__ uint32_t zigzag(int32_t s) {  // encode.rs:3845-3849
 // The f64 `ceil(log2(sum / n))` of encode.rs:3778-3780 is replaced by its exact integer
 // equivalent (smallest k with n * 2^k >= sum; valid because sum < 2^53).
 // ---------------------------------------------------------------------------------
+// residual arrays in LDS use a padded index (one extra dword per 16) so that lanes walking
+// contiguous 16-element runs (stride 17 dwords) hit distinct banks
+__device__ __forceinline__ uint32_t RIDX(uint32_t i) { return i + (i >> 4); }
+
 struct RiceShared {
     unsigned long long leaf[NLEAF];
-    uint32_t nd_est[NNODE], nd_cnt[NNODE];
-    uint8_t nd_kind[NNODE], nd_rice[NNODE], nd_esc[NNODE], nd_valid[NNODE];
-    uint32_t lv_est[MAXP + 1], lv_count[MAXP + 1];
-    uint8_t lv_valid[MAXP + 1];
-    int32_t best_p;        // -1: fallback (single 31-bit escaped partition)
-    uint32_t best_count, method;
+    unsigned long long pre[NLEAF + 1];   // exclusive prefix of the leaf sums
+    uint32_t nd_cnt[NNODE + 1];
+    uint8_t nd_kind[NNODE + 1], nd_rice[NNODE + 1], nd_esc[NNODE + 1];
+    uint32_t lv_est[MAXP + 1], lv_count[MAXP + 1], lv_bad[MAXP + 1], lv_hi[MAXP + 1];
     uint64_t red[4];
 };
 enum { PK_STANDARD = 0, PK_ESCAPED = 1, PK_CONSTANT = 2 };
@@ -224,170 +227,157 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
     if (P > MAXP) P = MAXP;  // host rejects such calls; clamp defensively
     const uint32_t leaf_len = n >> P;
     const uint32_t ept = (n + WG - 1) / WG;
-    const uint32_t lo = tid * ept;
-    const uint32_t hi = (lo + ept < n) ? lo + ept : n;
+    const uint32_t lo = tid * ept > order ? tid * ept : order;
+    const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
 
     if (tid < NLEAF) S.leaf[tid] = 0ull;
-    __syncthreads();
-    {
-        uint32_t i = lo > order ? lo : order;
-        if (i < hi) {
-            uint32_t cur = i / leaf_len;
-            uint32_t bound = (cur + 1) * leaf_len;
-            unsigned long long acc = 0;
-            for (; i < hi; i++) {
-                if (i == bound) {
-                    atomicAdd(&S.leaf[cur], acc);
-                    acc = 0;
-                    cur++;
-                    bound += leaf_len;
-                }
-                acc += uabs(r[i]);
-            }
-            atomicAdd(&S.leaf[cur], acc);
-        }
+    if (tid <= MAXP) {
+        S.lv_est[tid] = 0;
+        S.lv_count[tid] = 0;
+        S.lv_bad[tid] = 0;
+        S.lv_hi[tid] = 0;
     }
     __syncthreads();
-    // one thread per node of the partition tree: node id = 2^p + j  (1-based heap numbering)
-    if (tid < (2u << P) - 1u) {
-        uint32_t node = tid + 1;
-        uint32_t lvl = 31u - (uint32_t)__builtin_clz(node);
-        uint32_t j = node - (1u << lvl);
-        uint32_t plen = n >> lvl;
-        uint32_t start = j * plen, end = start + plen;
-        uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
-        uint32_t span = 1u << (P - lvl);
-        unsigned long long sum = 0;
-        for (uint32_t q = 0; q < span; q++) sum += S.leaf[j * span + q];
-        uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0, valid = 1;
-        uint32_t est = 0;
+    if (lo < hi) {  // this lane's contiguous run of residuals -> leaf sums
+        uint32_t i = lo;
+        uint32_t cur = i / leaf_len;
+        uint32_t bound = (cur + 1) * leaf_len;
+        unsigned long long acc = 0;
+        for (; i < hi; i++) {
+            if (i == bound) {
+                atomicAdd(&S.leaf[cur], acc);
+                acc = 0;
+                cur++;
+                bound += leaf_len;
+            }
+            acc += uabs(r[RIDX(i)]);
+        }
+        atomicAdd(&S.leaf[cur], acc);
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive prefix of the 64 leaf sums (one wave)
+        unsigned long long v = S.leaf[tid], incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long t = __shfl_up(incl, off, 64);
+            if (tid >= (uint32_t)off) incl += t;
+        }
+        S.pre[tid + 1] = incl;
+        if (tid == 0) S.pre[0] = 0;
+    }
+    __syncthreads();
+    // one lane per node of the partition tree, heap numbering: node = 2^level + j
+    if (tid >= 1 && tid < (2u << P)) {
+        const uint32_t node = tid;
+        const uint32_t lvl = 31u - (uint32_t)__builtin_clz(node);
+        const uint32_t j = node - (1u << lvl);
+        const uint32_t plen = n >> lvl;
+        const uint32_t start = j * plen, end = start + plen;
+        const uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
+        const uint32_t span = 1u << (P - lvl);
+        const unsigned long long sum = S.pre[(j + 1) * span] - S.pre[j * span];
+        uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0;
+        uint32_t est = 0, bad = 0;
         if (cnt > 0 && sum > 0) {
             uint32_t k = 0;
             bool standard = true;
             if (sum > (unsigned long long)cnt) {
-                unsigned long long q = (sum + cnt - 1) / cnt;  // ceil(sum / cnt) >= 2
-                k = 64u - (uint32_t)__clzll((long long)(q - 1));
+                // smallest k with cnt * 2^k >= sum (== ceil(log2(sum / cnt)), encode.rs:3778)
+                const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
+                const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
+                k = bs > bc ? bs - bc - 1 : 0;
+                while (((unsigned long long)cnt << k) < sum) k++;
                 if (k >= rice_max) {
                     standard = false;
-                    uint32_t e = (63u - (uint32_t)__clzll((long long)sum)) + 2u;  // ilog2(sum)+2
-                    if (e > 31u) valid = 0;
+                    const uint32_t e = (bs - 1) + 2u;  // ilog2(sum) + 2
+                    if (e > 31u) bad = 1;
                     kind = PK_ESCAPED;
                     esc = (uint8_t)e;
                     est = e * cnt;
                 }
             }
             if (standard) {
-                unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
-                if (t > 0xFFFFFFFFull) valid = 0;  // u32::try_from fails -> candidate dropped
+                const unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
+                if (t > 0xFFFFFFFFull) bad = 1;  // u32::try_from fails -> candidate dropped
                 kind = PK_STANDARD;
                 rice = (uint8_t)k;
                 est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
             }
         }
-        S.nd_kind[tid] = kind;
-        S.nd_rice[tid] = rice;
-        S.nd_esc[tid] = esc;
-        S.nd_valid[tid] = valid;
-        S.nd_est[tid] = est;
-        S.nd_cnt[tid] = cnt;
-    }
-    __syncthreads();
-    if (tid <= P) {
-        uint32_t lvl = tid, count = 0, est = 0;
-        bool ok = true;
-        for (uint32_t j = 0; j < (1u << lvl); j++) {
-            uint32_t nd = (1u << lvl) + j - 1u;
-            if (S.nd_cnt[nd] == 0) continue;  // chunk lies inside the warm-up: not a partition
-            count++;
-            if (!S.nd_valid[nd]) ok = false;
-            est += S.nd_est[nd];
+        S.nd_kind[node] = kind;
+        S.nd_rice[node] = rice;
+        S.nd_esc[node] = esc;
+        S.nd_cnt[node] = cnt;
+        if (cnt > 0) {  // chunks lying inside the warm-up are not partitions
+            atomicAdd(&S.lv_est[lvl], est);
+            atomicAdd(&S.lv_count[lvl], 1u);
+            if (bad) atomicOr(&S.lv_bad[lvl], 1u);
+            if (kind == PK_STANDARD && rice >= 15) atomicOr(&S.lv_hi[lvl], 1u);
         }
-        // encode.rs:3881 `!p.is_empty() && p.len().is_power_of_two()`
-        S.lv_valid[lvl] = ok && count > 0 && (count & (count - 1)) == 0;
-        S.lv_est[lvl] = est;
-        S.lv_count[lvl] = count;
     }
     __syncthreads();
-    if (tid == 0) {
-        int best = -1;
-        for (uint32_t lvl = 0; lvl <= P; lvl++)
-            if (S.lv_valid[lvl] && (best < 0 || S.lv_est[lvl] < S.lv_est[best])) best = (int)lvl;
-        S.best_p = best;  // min_by_key: first minimum wins
-        S.best_count = best >= 0 ? S.lv_count[best] : 1u;
-        S.method = 0;
+    // every lane picks the level: first minimum estimate among valid levels
+    // (encode.rs:3881 `!p.is_empty() && p.len().is_power_of_two()`, :3885 min_by_key)
+    int bp = -1;
+    uint32_t best_est = 0;
+    for (uint32_t lvl = 0; lvl <= P; lvl++) {
+        const uint32_t c = S.lv_count[lvl];
+        const bool ok = !S.lv_bad[lvl] && c > 0 && (c & (c - 1)) == 0;
+        if (ok && (bp < 0 || S.lv_est[lvl] < best_est)) {
+            bp = (int)lvl;
+            best_est = S.lv_est[lvl];
+        }
     }
-    __syncthreads();
-    const int bp = S.best_p;
-    const uint32_t count = S.best_count;
+    const uint32_t count = bp >= 0 ? S.lv_count[bp] : 1u;
+    // try_reduce_rice, encode.rs:3929-3942: RICE2 only if some parameter >= 15
+    const uint32_t method = (bp >= 0 && p.use_rice2 && S.lv_hi[bp]) ? 1u : 0u;
+    const uint32_t hb = method ? 5u : 4u;
     const uint32_t first_j = bp >= 0 ? (1u << bp) - count : 0u;  // chunks inside warm-up skipped
+    unsigned long long mine = 0;  // this lane's share of the residual block's bit count
     if (bp >= 0) {
         if (tid < count) {
-            uint32_t nd = (1u << bp) + first_j + tid - 1u;
+            const uint32_t nd = (1u << bp) + first_j + tid;
+            const uint32_t c = S.nd_cnt[nd];
             plan.rice[tid] = S.nd_rice[nd];
             plan.escape_bits[tid] = S.nd_esc[nd];
-            // try_reduce_rice, encode.rs:3929-3942: RICE2 only if some parameter >= 15
-            if (p.use_rice2 && S.nd_kind[nd] == PK_STANDARD && S.nd_rice[nd] >= 15)
-                atomicOr(&S.method, 1u);
+            if (S.nd_kind[nd] == PK_STANDARD) mine += hb + (1u + S.nd_rice[nd]) * c;
+            else if (S.nd_kind[nd] == PK_ESCAPED) mine += hb + 5u + (uint32_t)S.nd_esc[nd] * c;
+            else mine += hb + 5u;
         }
-    } else if (tid == 0) {
-        plan.rice[0] = 0xFF;
-        plan.escape_bits[0] = 31;  // encode.rs:3887-3895
-    }
-    __syncthreads();
-    // exact body bits: sum over standard partitions of (u >> k)
-    unsigned long long qsum = 0;
-    if (bp >= 0) {
-        const uint32_t plen = n >> bp;
-        uint32_t i = lo > order ? lo : order;
-        if (i < hi) {
+        if (lo < hi) {  // exact body bits: sum over standard partitions of (u >> k)
+            const uint32_t plen = n >> bp;
+            uint32_t i = lo;
             uint32_t cur = i / plen;
             uint32_t bound = (cur + 1) * plen;
-            uint32_t k = S.nd_rice[(1u << bp) + cur - 1u];
+            uint32_t k = S.nd_rice[(1u << bp) + cur];
             for (; i < hi; i++) {
                 if (i == bound) {
                     cur++;
                     bound += plen;
-                    k = S.nd_rice[(1u << bp) + cur - 1u];
+                    k = S.nd_rice[(1u << bp) + cur];
                 }
-                if (k != 0xFF) qsum += zigzag(r[i]) >> k;
+                if (k != 0xFF) mine += zigzag(r[RIDX(i)]) >> k;
             }
         }
+    } else {
+        if (tid == 0) {
+            plan.rice[0] = 0xFF;
+            plan.escape_bits[0] = 31;  // encode.rs:3887-3895
+            mine += hb + 5u + 31u * (n - order);
+        }
+        for (uint32_t i = lo; i < hi; i++)
+            if (r[RIDX(i)] < -(1 << 30) || r[RIDX(i)] >= (1 << 30)) mine |= 1ull << 52;  // does not fit 31 bits
     }
-    uint32_t bad = 0;
-    if (bp < 0)
-        for (uint32_t i = lo > order ? lo : order; i < hi; i++)
-            if (r[i] < -(1 << 30) || r[i] >= (1 << 30)) bad = 1;
-    qsum = block_sum_u64(qsum, S.red);
-    if (bp < 0) bad = block_or_u32(bad, S.red);
+    const unsigned long long tot = block_sum_u64(mine, S.red);
     if (tid == 0) {
-        const uint32_t hb = S.method ? 5u : 4u;
-        uint32_t bits = 2u + 4u;  // coding method + partition order (encode.rs:3949, 3902)
-        if (bp >= 0) {
-            for (uint32_t q = 0; q < count; q++) {
-                uint32_t nd = (1u << bp) + first_j + q - 1u;
-                uint32_t c = S.nd_cnt[nd];
-                if (S.nd_kind[nd] == PK_STANDARD)
-                    bits += hb + (1u + S.nd_rice[nd]) * c;
-                else if (S.nd_kind[nd] == PK_ESCAPED)
-                    bits += hb + 5u + (uint32_t)S.nd_esc[nd] * c;
-                else
-                    bits += hb + 5u;
-            }
-            bits += (uint32_t)qsum;
-            plan.part_len = n >> bp;
-        } else {
-            bits += hb + 5u + 31u * (n - order);
-            plan.part_len = n;
-        }
-        plan.coding_method = (uint8_t)S.method;
+        plan.part_len = bp >= 0 ? n >> bp : n;
+        plan.coding_method = (uint8_t)method;
         plan.n_partitions = count;
         plan.partition_order = (uint8_t)(31u - (uint32_t)__builtin_clz(count));
-        S.nd_est[0] = bits;
     }
-    __syncthreads();
-    resid_bits = S.nd_est[0];
-    __syncthreads();
-    return bad == 0;
+    // coding method (2) + partition order (4) (encode.rs:3949, 3902) + partitions
+    resid_bits = 6u + (uint32_t)(tot & 0xFFFFFFFFull);
+    return (tot >> 52) == 0;
 }
 
 __device__ __forceinline__ void plan_clear(SubPlan &plan) {
@@ -639,11 +629,13 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
         else if (order == 2) v = v - 2ll * x[i - 1] + x[i - 2];
         else if (order == 3) v = v - 3ll * x[i - 1] + 3ll * x[i - 2] - x[i - 3];
         else if (order == 4) v = v - 4ll * x[i - 1] + 6ll * x[i - 2] - 4ll * x[i - 3] + x[i - 4];
-        r[i] = (int32_t)v;
+        r[RIDX(i)] = (int32_t)v;
     }
     __syncthreads();
     uint32_t rbits;
-    const bool fixed_ok = rice_search(r, n, order, p, RS, plan, rbits);
+    uint32_t rb_ = 0;
+    const bool fixed_ok = (p.dbg & 1) ? true : rice_search(r, n, order, p, RS, plan, rb_);
+    rbits = rb_;
     if (tid == 0) {
         plan.reserved[0] = fixed_ok ? 0 : 1;  // internal: FIXED candidate is an Err
         plan.type = FLACGPU_SUB_FIXED;
@@ -968,15 +960,15 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
             int32_t pred = (int32_t)(sum >> shift);
             long long d = (long long)x[i] - (long long)pred;
             if (d < INT32_MIN || d > INT32_MAX) ovf = 1;  // checked_sub -> ResidualOverflow
-            r[i] = (int32_t)d;
+            r[RIDX(i)] = (int32_t)d;
         }
         ovf = block_or_u32(ovf, red);
         if (ovf) {
             lpc_ok = false;
             if (tid == 0) atomicAdd(&p.stats[0], 1u);
         } else {
-            uint32_t rbits;
-            if (!rice_search(r, n, order, p, RS, plan, rbits)) {
+            uint32_t rbits = 0;
+            if (!(p.dbg & 1) && !rice_search(r, n, order, p, RS, plan, rbits)) {
                 lpc_ok = false;
                 if (tid == 0) atomicAdd(&p.stats[0], 1u);
             }
@@ -1280,12 +1272,11 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     const uint32_t total_bits = prefix_bits + sub_bits;
     const uint32_t nwords = (total_bits + 31) / 32 + 1;
 
-    int32_t *r = lds;                                             // [block_size]
-    uint32_t *sb = reinterpret_cast<uint32_t *>(lds + p.block_size);  // bit string
+    uint32_t *sb = reinterpret_cast<uint32_t *>(lds);  // the subframe's bit string
     for (uint32_t i = tid; i < nwords; i += WG) sb[i] = 0;
-    const int32_t *row = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
-    const uint32_t nload = type == FLACGPU_SUB_CONSTANT ? 1u : n;
-    for (uint32_t i = tid; i < nload; i += WG) r[i] = row[i];
+    // residual row: every lane reads its own contiguous run straight from HBM/L2 (twice:
+    // lengths, then codes; the second pass hits L1/L2)
+    const int32_t *__restrict__ r = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
     __syncthreads();
 
     const uint32_t base = prefix_bits;  // bit where the subframe starts inside sb
@@ -1450,52 +1441,75 @@ __device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b) {  // a*b 
     }
     return r;
 }
+constexpr uint32_t CRC_CHUNK = 16384;  // bytes staged in LDS per pass: 256 lanes x 64 B
+
 __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
-    __shared__ uint16_t table[256];
+    __shared__ uint16_t T[4][256];                 // slicing-by-4 tables
+    __shared__ uint32_t buf[CRC_CHUNK / 4 + WG];   // one pad dword per 64-byte slice
     __shared__ uint32_t part[WG];
     const uint32_t frame = blockIdx.x, tid = threadIdx.x;
     {
         uint32_t c = tid << 8;
-        for (int b = 0; b < 8; b++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
-        table[tid] = (uint16_t)c;
+        for (int k = 0; k < 4; k++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
+            for (int b = 0; b < 8; b++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
+            T[k][tid] = (uint16_t)c;
+        }
     }
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(q.out_words);
     const uint64_t begin = q.frame_off[frame];
     const uint32_t len = (uint32_t)(q.frame_off[frame + 1] - begin) - 2;  // all but the CRC itself
-    const uint32_t m = (len + WG - 1) / WG;                               // slice length
-    __syncthreads();
-    // slices are aligned to the END of the frame; a short first slice acts as if it were
-    // left-padded with zero bytes, which leave a zero CRC state unchanged
-    const int64_t hi = (int64_t)len - (int64_t)(WG - 1 - tid) * m;
-    const int64_t lo = hi - m;
-    uint32_t crc = 0;
-    for (int64_t i = lo < 0 ? 0 : lo; i < hi; i++)
-        crc = (table[(crc >> 8) ^ bytes[begin + i]] ^ (crc << 8)) & 0xFFFF;
-    part[tid] = crc;
-    // x^(8m) mod P by square-and-multiply
-    uint32_t xp = 1, basep = 0x100 % 0x18005;  // x^8
-    {
-        uint32_t e = m, b2 = 0x100;
-        // reduce x^8 (degree 8 < 16: already reduced)
-        basep = b2;
-        while (e) {
-            if (e & 1) xp = gf_mulmod(xp, basep);
-            basep = gf_mulmod(basep, basep);
-            e >>= 1;
-        }
-    }
-    __syncthreads();
-    // tree: at each level the right operand spans `span` slices => shift the left by x^(8*m*span)
-    uint32_t shift = xp;
-    for (uint32_t span = 1; span < WG; span <<= 1) {
-        if ((tid & (2 * span - 1)) == 0) part[tid] = gf_mulmod(part[tid], shift) ^ part[tid + span];
-        shift = gf_mulmod(shift, shift);
+    // x^512 (one 64-byte slice) and x^(8*CRC_CHUNK) mod P
+    uint32_t x512 = 0x100;
+    for (int i = 0; i < 6; i++) x512 = gf_mulmod(x512, x512);
+    uint32_t xchunk = x512;
+    for (int i = 0; i < 8; i++) xchunk = gf_mulmod(xchunk, xchunk);  // (x^512)^256
+    uint32_t running = 0;
+    uint32_t pos = 0;
+    while (pos < len) {
+        // the FIRST pass takes the odd-sized head so every later pass is a full chunk; a chunk
+        // is right-aligned in the LDS window, i.e. left-padded with zero bytes, which leave a
+        // zero CRC state unchanged -- all 256 slices then have the same length
+        const uint32_t clen = (pos == 0 && (len % CRC_CHUNK)) ? len % CRC_CHUNK : CRC_CHUNK;
+        const uint32_t padb = CRC_CHUNK - clen;
         __syncthreads();
+        for (uint32_t d = tid; d < CRC_CHUNK / 4; d += WG) {
+            uint32_t v = 0;
+            const int64_t j0 = (int64_t)4 * d - padb;  // chunk byte index of this dword's first byte
+            if (j0 + 3 >= 0) {
+                const uint64_t src = begin + pos;
+                if (j0 >= 0 && ((src + j0) & 3) == 0) {
+                    v = *reinterpret_cast<const uint32_t *>(bytes + src + j0);
+                } else {
+                    for (int e = 0; e < 4; e++)
+                        if (j0 + e >= 0) v |= (uint32_t)bytes[src + j0 + e] << (8 * e);
+                }
+            }
+            buf[d + (d >> 4)] = v;
+        }
+        __syncthreads();
+        uint32_t crc = 0;
+        const uint32_t *sl = buf + tid * 17;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t v = sl[w];
+            crc = T[3][((crc >> 8) ^ v) & 0xFF] ^ T[2][(crc ^ (v >> 8)) & 0xFF] ^
+                  T[1][(v >> 16) & 0xFF] ^ T[0][v >> 24];
+        }
+        part[tid] = crc;
+        __syncthreads();
+        uint32_t shift = x512;
+        for (uint32_t span = 1; span < WG; span <<= 1) {
+            if ((tid & (2 * span - 1)) == 0) part[tid] = gf_mulmod(part[tid], shift) ^ part[tid + span];
+            shift = gf_mulmod(shift, shift);
+            __syncthreads();
+        }
+        running = gf_mulmod(running, xchunk) ^ part[0];
+        pos += clen;
     }
     if (tid == 0) {
         uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
-        ob[begin + len] = (uint8_t)(part[0] >> 8);
-        ob[begin + len + 1] = (uint8_t)part[0];
+        ob[begin + len] = (uint8_t)(running >> 8);
+        ob[begin + len + 1] = (uint8_t)running;
     }
 }
 
@@ -1611,7 +1625,7 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
 // dynamic LDS of k_pack: the residual row + the subframe's bit string (a chosen subframe is
 // never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
 size_t pack_lds_bytes(uint32_t block_size) {
-    return (size_t)block_size * 4 + ((size_t)block_size * 33 / 32 + 32) * 4;
+    return ((size_t)block_size * 33 / 32 + 32) * 4;
 }
 
 template <int H>
@@ -1710,10 +1724,10 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipStreamSynchronize(c->own_stream));
     if (int rc = upload_window(c, o->block_size, c->d_window_full, c->own_stream)) return rc;
     // k_fixed / k_fir use 2 * block_size * 4 bytes of dynamic LDS (up to 128 KiB of the 160)
-    const int dyn = (int)(2 * B * sizeof(int32_t));
+    const int dyn = (int)((2 * B + B / 16 + 16) * sizeof(int32_t));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, dyn / 2));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
     HIP_TRY(hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(pack_lds_bytes((uint32_t)B))));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -1776,6 +1790,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     p.use_rice2 = c->bps > 16;  // encode.rs:1965
     p.n_frames = n_frames;
     p.last_len = last_len;
+    { const char *e = getenv("FLACGPU_DEBUG"); p.dbg = e ? (uint32_t)atoi(e) : 0; }
     p.planar = c->d_planar;
     p.window_full = c->d_window_full;
     p.window_last = c->d_window_last;
@@ -1823,7 +1838,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
                                B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR);
     }
     const uint32_t ncb = n_frames * c->ncand;
-    const size_t dyn2 = 2 * (size_t)B * sizeof(int32_t);
+    const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
     if (c->stereo4 && !p.exhaustive) {
         begin(1);
         hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
@@ -1844,7 +1859,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
     begin(7);
-    hipLaunchKernelGGL(k_emit, dim3(n_frames * c->channels), dim3(WG), dyn2 / 2, st, p);
+    hipLaunchKernelGGL(k_emit, dim3(n_frames * c->channels), dim3(WG), (size_t)B * sizeof(int32_t), st, p);
     if (c->timing) (void)hipEventRecord(c->ev[evi], st);
     HIP_TRY(hipGetLastError());
     c->last_frames = n_frames;
