@@ -82,6 +82,7 @@ struct Params {
     uint32_t mid_side, exhaustive;
     uint32_t max_lpc_order, max_po, use_rice2;
     uint32_t n_frames, last_len;
+    uint32_t f0, fcount;                           // frames [f0, f0 + fcount) handled by this launch
     uint32_t dbg;                                  // timing experiments only (FLACGPU_DEBUG)
     // buffers
     const int32_t *planar;
@@ -215,21 +216,13 @@ struct RiceShared {
 };
 enum { PK_STANDARD = 0, PK_ESCAPED = 1, PK_CONSTANT = 2 };
 
-// Returns false when the reference's write_residuals would fail: only possible for the
-// 31-bit escaped fallback partition (encode.rs:3887-3895) when a residual does not fit 31
-// bits (`write_signed_counted` errors, :3857) -- the subframe candidate is then an Err.
-__device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const Params &p,
-                            RiceShared &S, SubPlan &plan /* LDS */, uint32_t &resid_bits) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
+__device__ __forceinline__ uint32_t rice_levels(uint32_t n, const Params &p) {
     uint32_t tz = (uint32_t)__builtin_ctz(n);
     uint32_t P = tz < p.max_po ? tz : p.max_po;
-    if (P > MAXP) P = MAXP;  // host rejects such calls; clamp defensively
-    const uint32_t leaf_len = n >> P;
-    const uint32_t ept = (n + WG - 1) / WG;
-    const uint32_t lo = tid * ept > order ? tid * ept : order;
-    const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
-
+    return P > MAXP ? MAXP : P;  // host rejects calls with P > 6; clamp defensively
+}
+__device__ __forceinline__ void rice_init(RiceShared &S) {
+    const uint32_t tid = threadIdx.x;
     if (tid < NLEAF) S.leaf[tid] = 0ull;
     if (tid <= MAXP) {
         S.lv_est[tid] = 0;
@@ -237,26 +230,18 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
         S.lv_bad[tid] = 0;
         S.lv_hi[tid] = 0;
     }
-    __syncthreads();
-    if (lo < hi) {  // this lane's contiguous run of residuals -> leaf sums
-        uint32_t i = lo;
-        uint32_t cur = i / leaf_len;
-        uint32_t bound = (cur + 1) * leaf_len;
-        unsigned long long acc = 0;
-        for (; i < hi; i++) {
-            if (i == bound) {
-                atomicAdd(&S.leaf[cur], acc);
-                acc = 0;
-                cur++;
-                bound += leaf_len;
-            }
-            acc += uabs(r[RIDX(i)]);
-        }
-        atomicAdd(&S.leaf[cur], acc);
-    }
-    __syncthreads();
+}
+
+// Partition tree evaluation.  Precondition: S.leaf[] holds the sums of |residual| of the
+// 2^P finest partitions and a barrier has been passed.  One lane per tree node runs
+// Partition::new (encode.rs:3765-3831); the f64 `ceil(log2(sum / n))` of :3778-3780 is
+// replaced by its exact integer equivalent (smallest k with n * 2^k >= sum; sum < 2^53).
+// Ends with a barrier; afterwards rice_pick() gives every lane the chosen level.
+__device__ __forceinline__ void rice_tree(RiceShared &S, uint32_t n, uint32_t order, uint32_t P,
+                                          uint32_t rice_max) {
+    const uint32_t tid = threadIdx.x;
     if (tid < 64) {  // exclusive prefix of the 64 leaf sums (one wave)
-        unsigned long long v = S.leaf[tid], incl = v;
+        unsigned long long incl = S.leaf[tid];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             unsigned long long t = __shfl_up(incl, off, 64);
@@ -266,7 +251,7 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
         if (tid == 0) S.pre[0] = 0;
     }
     __syncthreads();
-    // one lane per node of the partition tree, heap numbering: node = 2^level + j
+    // heap numbering: node = 2^level + j
     if (tid >= 1 && tid < (2u << P)) {
         const uint32_t node = tid;
         const uint32_t lvl = 31u - (uint32_t)__builtin_clz(node);
@@ -282,7 +267,6 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
             uint32_t k = 0;
             bool standard = true;
             if (sum > (unsigned long long)cnt) {
-                // smallest k with cnt * 2^k >= sum (== ceil(log2(sum / cnt)), encode.rs:3778)
                 const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
                 const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
                 k = bs > bc ? bs - bc - 1 : 0;
@@ -316,45 +300,109 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
         }
     }
     __syncthreads();
-    // every lane picks the level: first minimum estimate among valid levels
-    // (encode.rs:3881 `!p.is_empty() && p.len().is_power_of_two()`, :3885 min_by_key)
-    int bp = -1;
+}
+
+struct RicePick {
+    int bp;            // chosen partition level, -1 = 31-bit escaped fallback (encode.rs:3887)
+    uint32_t count;    // partitions emitted
+    uint32_t method;   // 0 RICE, 1 RICE2
+    uint32_t first_j;  // chunks of level bp lying wholly inside the warm-up
+};
+// first minimum estimate among valid levels (encode.rs:3881 `!p.is_empty() &&
+// p.len().is_power_of_two()`, :3885 min_by_key); try_reduce_rice (:3929-3942)
+__device__ __forceinline__ RicePick rice_pick(const RiceShared &S, uint32_t P, uint32_t use_rice2) {
+    RicePick r;
+    r.bp = -1;
     uint32_t best_est = 0;
     for (uint32_t lvl = 0; lvl <= P; lvl++) {
         const uint32_t c = S.lv_count[lvl];
         const bool ok = !S.lv_bad[lvl] && c > 0 && (c & (c - 1)) == 0;
-        if (ok && (bp < 0 || S.lv_est[lvl] < best_est)) {
-            bp = (int)lvl;
+        if (ok && (r.bp < 0 || S.lv_est[lvl] < best_est)) {
+            r.bp = (int)lvl;
             best_est = S.lv_est[lvl];
         }
     }
-    const uint32_t count = bp >= 0 ? S.lv_count[bp] : 1u;
-    // try_reduce_rice, encode.rs:3929-3942: RICE2 only if some parameter >= 15
-    const uint32_t method = (bp >= 0 && p.use_rice2 && S.lv_hi[bp]) ? 1u : 0u;
-    const uint32_t hb = method ? 5u : 4u;
-    const uint32_t first_j = bp >= 0 ? (1u << bp) - count : 0u;  // chunks inside warm-up skipped
-    unsigned long long mine = 0;  // this lane's share of the residual block's bit count
-    if (bp >= 0) {
-        if (tid < count) {
-            const uint32_t nd = (1u << bp) + first_j + tid;
-            const uint32_t c = S.nd_cnt[nd];
-            plan.rice[tid] = S.nd_rice[nd];
-            plan.escape_bits[tid] = S.nd_esc[nd];
-            if (S.nd_kind[nd] == PK_STANDARD) mine += hb + (1u + S.nd_rice[nd]) * c;
-            else if (S.nd_kind[nd] == PK_ESCAPED) mine += hb + 5u + (uint32_t)S.nd_esc[nd] * c;
-            else mine += hb + 5u;
+    r.count = r.bp >= 0 ? S.lv_count[r.bp] : 1u;
+    r.method = (r.bp >= 0 && use_rice2 && S.lv_hi[r.bp]) ? 1u : 0u;
+    r.first_j = r.bp >= 0 ? (1u << r.bp) - r.count : 0u;
+    return r;
+}
+// header + fixed part of partition `tid` of the chosen level, and the plan's parameter arrays
+__device__ __forceinline__ unsigned long long rice_partition_fixed_bits(const RiceShared &S,
+                                                                        const RicePick &pk,
+                                                                        SubPlan &plan) {
+    const uint32_t tid = threadIdx.x, hb = pk.method ? 5u : 4u;
+    if (tid >= pk.count) return 0;
+    const uint32_t nd = (1u << pk.bp) + pk.first_j + tid;
+    const uint32_t c = S.nd_cnt[nd];
+    plan.rice[tid] = S.nd_rice[nd];
+    plan.escape_bits[tid] = S.nd_esc[nd];
+    if (S.nd_kind[nd] == PK_STANDARD) return hb + (1u + S.nd_rice[nd]) * c;
+    if (S.nd_kind[nd] == PK_ESCAPED) return hb + 5u + (uint32_t)S.nd_esc[nd] * c;
+    return hb + 5u;
+}
+__device__ __forceinline__ bool rice_finish(RiceShared &S, const RicePick &pk, uint32_t n,
+                                            unsigned long long mine, SubPlan &plan,
+                                            uint32_t &resid_bits) {
+    const unsigned long long tot = block_sum_u64(mine, S.red);
+    if (threadIdx.x == 0) {
+        plan.part_len = pk.bp >= 0 ? n >> pk.bp : n;
+        plan.coding_method = (uint8_t)pk.method;
+        plan.n_partitions = pk.count;
+        plan.partition_order = (uint8_t)(31u - (uint32_t)__builtin_clz(pk.count));
+    }
+    // coding method (2) + partition order (4) (encode.rs:3949, 3902) + partitions
+    resid_bits = 6u + (uint32_t)(tot & 0xFFFFFFFFull);
+    return (tot >> 52) == 0;
+}
+
+// Generic Rice search over a residual array in LDS (any block length).
+// Returns false when the reference's write_residuals would fail: only possible for the
+// 31-bit escaped fallback partition (encode.rs:3887-3895) when a residual does not fit 31
+// bits (`write_signed_counted` errors, :3857) -- the subframe candidate is then an Err.
+__device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const Params &p,
+                            RiceShared &S, SubPlan &plan /* LDS */, uint32_t &resid_bits) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = rice_levels(n, p);
+    const uint32_t leaf_len = n >> P;
+    const uint32_t ept = (n + WG - 1) / WG;
+    const uint32_t lo = tid * ept > order ? tid * ept : order;
+    const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
+    rice_init(S);
+    __syncthreads();
+    if (lo < hi) {  // this lane's contiguous run of residuals -> leaf sums
+        uint32_t i = lo;
+        uint32_t cur = i / leaf_len;
+        uint32_t bound = (cur + 1) * leaf_len;
+        unsigned long long acc = 0;
+        for (; i < hi; i++) {
+            if (i == bound) {
+                atomicAdd(&S.leaf[cur], acc);
+                acc = 0;
+                cur++;
+                bound += leaf_len;
+            }
+            acc += uabs(r[RIDX(i)]);
         }
+        atomicAdd(&S.leaf[cur], acc);
+    }
+    __syncthreads();
+    rice_tree(S, n, order, P, p.use_rice2 ? 31u : 15u);
+    const RicePick pk = rice_pick(S, P, p.use_rice2);
+    unsigned long long mine = 0;  // this lane's share of the residual block's bit count
+    if (pk.bp >= 0) {
+        mine += rice_partition_fixed_bits(S, pk, plan);
         if (lo < hi) {  // exact body bits: sum over standard partitions of (u >> k)
-            const uint32_t plen = n >> bp;
+            const uint32_t plen = n >> pk.bp;
             uint32_t i = lo;
             uint32_t cur = i / plen;
             uint32_t bound = (cur + 1) * plen;
-            uint32_t k = S.nd_rice[(1u << bp) + cur];
+            uint32_t k = S.nd_rice[(1u << pk.bp) + cur];
             for (; i < hi; i++) {
                 if (i == bound) {
                     cur++;
                     bound += plen;
-                    k = S.nd_rice[(1u << bp) + cur];
+                    k = S.nd_rice[(1u << pk.bp) + cur];
                 }
                 if (k != 0xFF) mine += zigzag(r[RIDX(i)]) >> k;
             }
@@ -363,21 +411,53 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
         if (tid == 0) {
             plan.rice[0] = 0xFF;
             plan.escape_bits[0] = 31;  // encode.rs:3887-3895
-            mine += hb + 5u + 31u * (n - order);
+            mine += 4u + 5u + 31u * (n - order);
         }
         for (uint32_t i = lo; i < hi; i++)
-            if (r[RIDX(i)] < -(1 << 30) || r[RIDX(i)] >= (1 << 30)) mine |= 1ull << 52;  // does not fit 31 bits
+            if (r[RIDX(i)] < -(1 << 30) || r[RIDX(i)] >= (1 << 30)) mine |= 1ull << 52;  // > 31 bits
     }
-    const unsigned long long tot = block_sum_u64(mine, S.red);
-    if (tid == 0) {
-        plan.part_len = bp >= 0 ? n >> bp : n;
-        plan.coding_method = (uint8_t)method;
-        plan.n_partitions = count;
-        plan.partition_order = (uint8_t)(31u - (uint32_t)__builtin_clz(count));
+    return rice_finish(S, pk, n, mine, plan, resid_bits);
+}
+
+// Fast path: block of exactly 4096 samples, lane t holds the residuals of samples
+// [16 t, 16 t + 16) in registers (v[e] valid for 16 t + e >= order).  Same decisions as
+// rice_search, no residual array in LDS.
+constexpr uint32_t FN = 4096;
+__device__ bool rice16(const int32_t (&v)[16], uint32_t order, const Params &p, RiceShared &S,
+                       SubPlan &plan /* LDS */, uint32_t &resid_bits) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = rice_levels(FN, p);
+    const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
+    rice_init(S);
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        if ((uint32_t)e >= first) acc += uabs(v[e]);
+    __syncthreads();
+    atomicAdd(&S.leaf[(16 * tid) >> (12 - P)], acc);  // leaf length = 4096 >> P >= 64
+    __syncthreads();
+    rice_tree(S, FN, order, P, p.use_rice2 ? 31u : 15u);
+    const RicePick pk = rice_pick(S, P, p.use_rice2);
+    unsigned long long mine = 0;
+    if (pk.bp >= 0) {
+        mine += rice_partition_fixed_bits(S, pk, plan);
+        const uint32_t k = S.nd_rice[(1u << pk.bp) + ((16 * tid) >> (12 - pk.bp))];
+        if (k != 0xFF) {
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                if ((uint32_t)e >= first) mine += zigzag(v[e]) >> k;
+        }
+    } else {
+        if (tid == 0) {
+            plan.rice[0] = 0xFF;
+            plan.escape_bits[0] = 31;
+            mine += 4u + 5u + 31u * (FN - order);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if ((uint32_t)e >= first && (v[e] < -(1 << 30) || v[e] >= (1 << 30))) mine |= 1ull << 52;
     }
-    // coding method (2) + partition order (4) (encode.rs:3949, 3902) + partitions
-    resid_bits = 6u + (uint32_t)(tot & 0xFFFFFFFFull);
-    return (tot >> 52) == 0;
+    return rice_finish(S, pk, FN, mine, plan, resid_bits);
 }
 
 __device__ __forceinline__ void plan_clear(SubPlan &plan) {
@@ -507,7 +587,8 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
     __shared__ uint64_t sums[5];
 
     uint32_t frame, cand;
-    map_block(blockIdx.x, p.ncand, p.n_frames, frame, cand);
+    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
+    frame += p.f0;
     const uint32_t n = frame_len(p, frame);
     const size_t cidx = (size_t)frame * p.ncand + cand;
     const uint32_t tid = threadIdx.x;
@@ -932,7 +1013,8 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
     __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
 
     uint32_t frame, cand;
-    map_block(blockIdx.x, p.ncand, p.n_frames, frame, cand);
+    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
+    frame += p.f0;
     const uint32_t n = frame_len(p, frame);
     const size_t cidx = (size_t)frame * p.ncand + cand;
     const uint32_t tid = threadIdx.x;
@@ -982,6 +1064,299 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
     // (Ok,Ok) -> min_by_key(written) with FIXED first: tie keeps FIXED; (Err,Ok) -> LPC;
     // (Ok,Err) -> FIXED; (Err,Err) -> VERBATIM (encode.rs:2929-2945)
     const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);
+    const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
+    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < n * bps_eff);  // :2971-2979
+    if (verbatim) {
+        __syncthreads();
+        plan_clear(plan);
+        __syncthreads();
+        if (tid == 0) make_verbatim(plan, n, bps_eff, wasted, src.source);
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    } else if (use_lpc) {
+        if (tid == 0) {
+            plan.type = FLACGPU_SUB_LPC;
+            plan.wasted = (uint8_t)wasted;
+            plan.bps = (uint8_t)bps_eff;
+            plan.order = lp->order;
+            plan.precision = lp->precision;
+            plan.shift = lp->shift;
+            plan.source = src.source;
+            plan.bits = lpc_bits;
+        }
+        if (tid < FLACGPU_MAX_LPC_ORDER) plan.coeffs[tid] = qlp[tid];
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    } else {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(fx);
+        uint32_t *d = reinterpret_cast<uint32_t *>(p.cand_plan + cidx);
+        for (uint32_t i = tid; i < sizeof(SubPlan) / 4; i += WG) d[i] = s[i];
+    }
+}
+
+// =================================================================================
+// Fast path for blocks of exactly 4096 samples (the default block size of every preset but
+// `fast`): lane t of the 256-thread workgroup owns samples [16 t, 16 t + 16) IN REGISTERS;
+// all per-sample loops are statically unrolled, neighbours come through a small LDS halo, no
+// per-block arrays live in LDS (occupancy is register-bound).  Decisions are identical to the
+// generic kernels (same helpers).  Requires candidate bps <= 27 so that 4th-order differences
+// stay inside i32 (the generic kernels handle wider input).
+// =================================================================================
+__device__ __forceinline__ void load_cand16(const CandSrc &src, uint32_t t, int32_t (&x)[16]) {
+    const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 4 * t;
+    int4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = pa[q];
+    if (src.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            x[4 * q] = a[q].x; x[4 * q + 1] = a[q].y; x[4 * q + 2] = a[q].z; x[4 * q + 3] = a[q].w;
+        }
+    } else {
+        const int4 *pb = reinterpret_cast<const int4 *>(src.b) + 4 * t;
+        int4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = pb[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            x[4 * q] = combine(src.mode, a[q].x, b[q].x);
+            x[4 * q + 1] = combine(src.mode, a[q].y, b[q].y);
+            x[4 * q + 2] = combine(src.mode, a[q].z, b[q].z);
+            x[4 * q + 3] = combine(src.mode, a[q].w, b[q].w);
+        }
+    }
+}
+
+// five u64 sums over the workgroup with one barrier pair; scratch holds 4 * 5 u64
+__device__ __forceinline__ void block_sum5(uint64_t (&v)[5], uint64_t *scratch) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = wave_sum_u64(v[k]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) scratch[(threadIdx.x >> 6) * 5 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = scratch[k] + scratch[5 + k] + scratch[10 + k] + scratch[15 + k];
+}
+
+__global__ void __launch_bounds__(WG) k_fixed16(Params p) {
+    __shared__ RiceShared RS;
+    __shared__ SubPlan plan;
+    __shared__ uint64_t red[20];
+    __shared__ int4 halo[WG];
+
+    uint32_t frame, cand;
+    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
+    frame += p.f0;
+    const uint32_t n = FN;
+    const size_t cidx = (size_t)frame * p.ncand + cand;
+    const uint32_t tid = threadIdx.x;
+    CandInfo *ci = p.cinfo + cidx;
+    if (p.exhaustive || !p.stereo4) {
+        if (p.stereo4 && cand == 2 && !p.mid_side) {
+            if (tid == 0) ci->active = 0;
+            return;
+        }
+        if (tid == 0) ci->active = 1;
+    } else if (!ci->active) {
+        return;
+    }
+    const CandSrc src = cand_src(p, frame, cand);
+    int32_t x[16];
+    load_cand16(src, tid, x);
+    uint32_t orv = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) orv |= (uint32_t)x[e];
+    orv = block_or_u32(orv, red);
+    plan_clear(plan);
+    const uint32_t wasted = orv ? (uint32_t)__builtin_ctz(orv) : 32u;  // encode.rs:2878-2898
+    if (wasted == 32u) {
+        __syncthreads();
+        if (tid == 0) {
+            plan.type = FLACGPU_SUB_CONSTANT;
+            plan.bps = (uint8_t)src.bps;
+            plan.source = src.source;
+            plan.bits = 8u + src.bps;
+            ci->wasted = 0;
+            ci->bps = (uint8_t)src.bps;
+            ci->is_const = 1;
+        }
+        __syncthreads();
+        plan_store(p.fixed_plan + cidx, plan);
+        plan_store(p.cand_plan + cidx, plan);
+        return;
+    }
+    const uint32_t bps_eff = src.bps - wasted;
+#pragma unroll
+    for (int e = 0; e < 16; e++) x[e] >>= wasted;
+    halo[tid] = make_int4(x[12], x[13], x[14], x[15]);
+    __syncthreads();
+    int32_t q[20];
+    {
+        const int4 h = tid ? halo[tid - 1] : make_int4(0, 0, 0, 0);
+        q[0] = h.x; q[1] = h.y; q[2] = h.z; q[3] = h.w;
+#pragma unroll
+        for (int e = 0; e < 16; e++) q[4 + e] = x[e];
+    }
+    // residuals of orders 1..4 (i32 exact: |x| < 2^26) and abs sums over [4, n), encode.rs:3039-3073
+    int32_t d1[16], d2[16], d3[16], d4[16];
+    uint64_t sm[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int32_t x0 = q[e + 4], x1 = q[e + 3], x2 = q[e + 2], x3 = q[e + 1], x4 = q[e];
+        d1[e] = x0 - x1;
+        d2[e] = x0 - 2 * x1 + x2;
+        d3[e] = x0 - 3 * x1 + 3 * x2 - x3;
+        d4[e] = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
+        if (tid > 0 || e >= 4) {
+            sm[0] += uabs(x0);
+            sm[1] += uabs(d1[e]);
+            sm[2] += uabs(d2[e]);
+            sm[3] += uabs(d3[e]);
+            sm[4] += uabs(d4[e]);
+        }
+    }
+    block_sum5(sm, red);
+    uint32_t order = 0;
+#pragma unroll
+    for (uint32_t k = 1; k <= 4; k++)
+        if (sm[k] < sm[order]) order = k;  // min_by_key: first minimum wins
+    int32_t res[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        res[e] = order == 0 ? x[e] : order == 1 ? d1[e] : order == 2 ? d2[e] : order == 3 ? d3[e] : d4[e];
+    uint32_t rbits = 0;
+    const bool fixed_ok = rice16(res, order, p, RS, plan, rbits);
+    if (tid == 0) {
+        plan.reserved[0] = fixed_ok ? 0 : 1;
+        plan.type = FLACGPU_SUB_FIXED;
+        plan.wasted = (uint8_t)wasted;
+        plan.bps = (uint8_t)bps_eff;
+        plan.order = (uint8_t)order;
+        plan.source = src.source;
+        plan.bits = 8u + wasted + order * bps_eff + rbits;
+        ci->wasted = (uint8_t)wasted;
+        ci->bps = (uint8_t)bps_eff;
+        ci->is_const = 0;
+    }
+    __syncthreads();
+    plan_store(p.fixed_plan + cidx, plan);
+    if (p.max_lpc_order == 0) {
+        __syncthreads();
+        const bool verbatim = !fixed_ok || !(plan.bits < n * bps_eff);
+        __syncthreads();
+        if (verbatim) plan_clear(plan);
+        __syncthreads();
+        if (tid == 0 && verbatim) make_verbatim(plan, n, bps_eff, wasted, src.source);
+        __syncthreads();
+        plan_store(p.cand_plan + cidx, plan);
+    }
+}
+
+// FIR over a register window: pw[0..31] = the 32 samples before this lane's run, pw[32..47] its
+// own 16 samples; T taps (order rounded up to 4, missing coefficients are zero)
+template <int T>
+__device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[48], const int32_t *qlp /* LDS */,
+                                          uint32_t shift, uint32_t first, int32_t (&res)[16]) {
+    int32_t c[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) c[j] = qlp[j];
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        long long sum = 0;
+#pragma unroll
+        for (int j = 0; j < T; j++) sum += (long long)pw[32 + e - 1 - j] * (long long)c[j];
+        const int32_t pred = (int32_t)(sum >> shift);
+        const long long d = (long long)pw[32 + e] - (long long)pred;
+        if ((uint32_t)e >= first && (d < INT32_MIN || d > INT32_MAX)) ovf = 1;  // ResidualOverflow
+        res[e] = (int32_t)d;
+    }
+    return ovf;
+}
+
+__global__ void __launch_bounds__(WG) k_fir16(Params p) {
+    __shared__ RiceShared RS;
+    __shared__ SubPlan plan;
+    __shared__ uint64_t red[4];
+    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+    __shared__ __attribute__((aligned(16))) int32_t xs[WG * 20];  // 16 samples + 4 pad per lane
+
+    uint32_t frame, cand;
+    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
+    frame += p.f0;
+    const uint32_t n = FN;
+    const size_t cidx = (size_t)frame * p.ncand + cand;
+    const uint32_t tid = threadIdx.x;
+    const CandInfo ci = p.cinfo[cidx];
+    if (!ci.active || ci.is_const) return;
+    const LpcParams *lp = p.lpc + cidx;
+    const CandSrc src = cand_src(p, frame, cand);
+    const uint32_t wasted = ci.wasted, bps_eff = ci.bps;
+    bool lpc_ok = lp->status == 0;
+    uint32_t lpc_bits = 0;
+    plan_clear(plan);
+    if (lpc_ok) {
+        const uint32_t order = lp->order, shift = lp->shift;
+        if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = tid < order ? lp->qlp[tid] : 0;
+        int32_t pw[48];
+        {
+            int32_t x[16];
+            load_cand16(src, tid, x);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                x[e] >>= wasted;
+                pw[32 + e] = x[e];
+            }
+            int4 *row = reinterpret_cast<int4 *>(xs + tid * 20);
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) row[qd] = make_int4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {  // rows tid-2, tid-1
+            const int srcrow = (int)tid - 2 + rr;
+            const int4 *row = reinterpret_cast<const int4 *>(xs + (srcrow < 0 ? 0 : srcrow) * 20);
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int4 v = srcrow < 0 ? make_int4(0, 0, 0, 0) : row[qd];
+                pw[16 * rr + 4 * qd] = v.x; pw[16 * rr + 4 * qd + 1] = v.y;
+                pw[16 * rr + 4 * qd + 2] = v.z; pw[16 * rr + 4 * qd + 3] = v.w;
+            }
+        }
+        const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
+        int32_t res[16];
+        uint32_t ovf;
+        switch ((order + 3) >> 2) {  // encode_residuals, encode.rs:3181-3197
+        case 1: ovf = fir16<4>(pw, qlp, shift, first, res); break;
+        case 2: ovf = fir16<8>(pw, qlp, shift, first, res); break;
+        case 3: ovf = fir16<12>(pw, qlp, shift, first, res); break;
+        case 4: ovf = fir16<16>(pw, qlp, shift, first, res); break;
+        case 5: ovf = fir16<20>(pw, qlp, shift, first, res); break;
+        case 6: ovf = fir16<24>(pw, qlp, shift, first, res); break;
+        case 7: ovf = fir16<28>(pw, qlp, shift, first, res); break;
+        default: ovf = fir16<32>(pw, qlp, shift, first, res); break;
+        }
+        ovf = block_or_u32(ovf, red);
+        if (ovf) {
+            lpc_ok = false;
+            if (tid == 0) atomicAdd(&p.stats[0], 1u);
+        } else {
+            uint32_t rbits = 0;
+            if (!rice16(res, order, p, RS, plan, rbits)) {
+                lpc_ok = false;
+                if (tid == 0) atomicAdd(&p.stats[0], 1u);
+            }
+            lpc_bits = 8u + wasted + order * bps_eff + 4u + 5u + order * lp->precision + rbits;
+        }
+    }
+    __syncthreads();
+    const SubPlan *fx = p.fixed_plan + cidx;
+    const uint32_t fixed_bits = fx->bits;
+    const bool fixed_ok = fx->reserved[0] == 0;
+    const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);  // encode.rs:2929-2945
     const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
     const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < n * bps_eff);  // :2971-2979
     if (verbatim) {
@@ -1078,7 +1453,8 @@ __global__ void __launch_bounds__(WG) k_emit(Params p) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
     uint32_t frame, ch;
-    map_block(blockIdx.x, p.channels, p.n_frames, frame, ch);
+    map_block(blockIdx.x, p.channels, p.fcount, frame, ch);
+    frame += p.f0;
     const uint32_t n = frame_len(p, frame);
     const uint32_t tid = threadIdx.x;
     const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
@@ -1255,7 +1631,8 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint8_t hdr[16];
     uint32_t frame, ch;
-    map_block(blockIdx.x, p.channels, p.n_frames, frame, ch);
+    map_block(blockIdx.x, p.channels, p.fcount, frame, ch);
+    frame += p.f0;
     const uint32_t tid = threadIdx.x;
     const uint32_t n = frame_len(p, frame);
     const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
@@ -1790,6 +2167,8 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     p.use_rice2 = c->bps > 16;  // encode.rs:1965
     p.n_frames = n_frames;
     p.last_len = last_len;
+    p.f0 = 0;
+    p.fcount = n_frames;
     { const char *e = getenv("FLACGPU_DEBUG"); p.dbg = e ? (uint32_t)atoi(e) : 0; }
     p.planar = c->d_planar;
     p.window_full = c->d_window_full;
@@ -1844,7 +2223,17 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
     }
     begin(2);
-    hipLaunchKernelGGL(k_fixed, dim3(ncb), dim3(WG), dyn2, st, p);
+    // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
+    // block sizes, a short last frame, candidates wider than 27 bits) the generic LDS ones
+    const bool fast16 = (B == FN) && (c->bps + (c->stereo4 ? 1u : 0u) <= 27u) && !getenv("FLACGPU_NO_FAST");
+    const uint32_t n_fast = fast16 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
+    Params pf = p, pg = p;
+    pf.f0 = 0;
+    pf.fcount = n_fast;
+    pg.f0 = n_fast;
+    pg.fcount = n_frames - n_fast;
+    if (pf.fcount) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
+    if (pg.fcount) hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     if (p.max_lpc_order > 0) {
         const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
         begin(3);
@@ -1854,7 +2243,8 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         begin(4);
         hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
         begin(5);
-        hipLaunchKernelGGL(k_fir, dim3(ncb), dim3(WG), dyn2, st, p);
+        if (pf.fcount) hipLaunchKernelGGL(k_fir16, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
+        if (pg.fcount) hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
