@@ -843,6 +843,159 @@ __global__ void __launch_bounds__(64) k_autocorr(Params p, uint32_t frame0, uint
 }
 
 // ---------------------------------------------------------------------------------
+// K3 (tiled): same arithmetic and summation order as ac_body, but the samples reach the lanes
+// through LDS.  A 256-thread workgroup serves 64 candidates; its 4 waves are the 4 lag groups.
+// Per tile of TS samples:
+//   1. the planar rows those candidates need (<= 72) are staged with coalesced 16-byte loads
+//      (global -> registers for tile i+1 is issued while tile i is consumed);
+//   2. all 256 lanes together turn them into the candidates' WINDOWED f64 samples
+//      (mid/side derivation, wasted-bit shift, (f64)x * w[i], encode.rs:1799) exactly once;
+//   3. every wave walks the 64 f64 columns for its lag group: one LDS read + LG mul/add pairs
+//      per sample, ring of the last H values in registers, statically indexed.
+// ---------------------------------------------------------------------------------
+constexpr int AC_MAXROWS = 72;
+
+template <int H, int A, int LG, bool FIRST, bool GUARDED>
+__device__ __forceinline__ void ac_block_w(double (&hist)[H], double (&acc)[LG], const double *tw,
+                                           uint32_t col0, uint32_t base, uint32_t n) {
+    double w[H];
+#pragma unroll
+    for (int s = 0; s < H; s++) w[s] = tw[col0 + s];
+#pragma unroll
+    for (int s = 0; s < H; s++) {
+        hist[s] = w[s];
+        if (!GUARDED || base + s < n) {
+#pragma unroll
+            for (int k = 0; k < LG; k++) {
+                const int lag = A + k;
+                if (!FIRST || s >= lag) {
+                    const double prod = w[s] * hist[(s - lag + 2 * H) % H];
+                    acc[k] = acc[k] + prod;
+                }
+            }
+        }
+    }
+}
+
+template <int H, int A, int LG, int KB, int LDT, int LDW>
+__device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXROWS * LDT],
+                                        double *wt, uint32_t frame0, uint32_t nframes, uint32_t n,
+                                        const double *__restrict__ win) {
+    constexpr int TS = H * KB;          // samples per tile
+    constexpr int Q = TS / 4;           // int4 per row per tile
+    constexpr int NLOAD = (AC_MAXROWS * Q + WG - 1) / WG;
+    constexpr int CW = (TS + 3) / 4;    // columns converted per wave
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t total = nframes * p.ncand;
+    const uint32_t cand0 = blockIdx.x * 64;
+    const uint32_t last_c = cand0 + 63 < total ? cand0 + 63 : total - 1;
+    const bool live = cand0 + lane < total;
+    const uint32_t cc = live ? cand0 + lane : last_c;
+    const uint32_t f_lo = cand0 / p.ncand, f_hi = last_c / p.ncand;
+    const uint32_t frame = frame0 + cc / p.ncand;
+    const uint32_t cand = cc % p.ncand;
+    const uint32_t nrows = (f_hi - f_lo + 1) * p.channels;
+    const int32_t *gbase = p.planar + (size_t)(frame0 + f_lo) * p.channels * p.ldb;
+    // this lane's two source rows inside the staged set
+    uint32_t ca = cand, cb = cand;
+    int mode = 0;
+    if (p.stereo4) {
+        if (cand >= 2) { ca = 0; cb = 1; mode = cand == 2 ? 1 : 2; }
+    }
+    const uint32_t ra = (cc / p.ncand - f_lo) * p.channels + ca;
+    const uint32_t rb = (cc / p.ncand - f_lo) * p.channels + cb;
+    const CandInfo ci = p.cinfo[(size_t)frame * p.ncand + cand];
+    const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
+
+    double hist[H], acc[LG];
+#pragma unroll
+    for (int k = 0; k < LG; k++) acc[k] = -0.0;  // f64 `sum()` identity
+#pragma unroll
+    for (int s = 0; s < H; s++) hist[s] = 0.0;
+
+    const uint32_t ntiles = (n + TS - 1) / TS;
+    int4 stage[NLOAD];
+    auto fetch = [&](uint32_t t) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+            const uint32_t idx = tid + k * WG;
+            const uint32_t r = idx / Q, c4 = idx - r * Q;
+            const uint32_t col = t * TS + 4 * c4;
+            stage[k] = (r < nrows && col < p.ldb)
+                           ? *reinterpret_cast<const int4 *>(gbase + (size_t)r * p.ldb + col)
+                           : make_int4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&](uint32_t buf) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+            const uint32_t idx = tid + k * WG;
+            const uint32_t r = idx / Q, c4 = idx - r * Q;
+            if (r < AC_MAXROWS) *reinterpret_cast<int4 *>(&tile[buf][r * LDT + 4 * c4]) = stage[k];
+        }
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    double *tw = wt + lane * LDW;  // this lane's candidate row of windowed samples
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint32_t buf = t & 1;
+        const uint32_t tbase = t * TS;
+        if (t + 1 < ntiles) fetch(t + 1);
+        {   // step 2: wave `wave` converts columns [wave*CW, wave*CW + CW) of all 64 candidates
+            const int32_t *ta = &tile[buf][ra * LDT];
+            const int32_t *tb = &tile[buf][rb * LDT];
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                const uint32_t col = wave * CW + c;
+                if (col < (uint32_t)TS) {
+                    const int32_t v = combine(mode, ta[col], tb[col]) >> wasted;
+                    tw[col] = (double)v * win[tbase + col];
+                }
+            }
+        }
+        __syncthreads();
+        if (tbase + TS <= n && t > 0) {
+#pragma unroll 1
+            for (int b = 0; b < KB; b++)
+                ac_block_w<H, A, LG, false, false>(hist, acc, tw, b * H, tbase + b * H, n);
+        } else {
+#pragma unroll 1
+            for (int b = 0; b < KB; b++) {
+                const uint32_t base = tbase + b * H;
+                if (base >= n) break;
+                if (base == 0) ac_block_w<H, A, LG, true, true>(hist, acc, tw, b * H, base, n);
+                else ac_block_w<H, A, LG, false, true>(hist, acc, tw, b * H, base, n);
+            }
+        }
+        if (t + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+    if (live) {
+        double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
+#pragma unroll
+        for (int k = 0; k < LG; k++) out[k] = acc[k];
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(WG) k_autocorr2(Params p, uint32_t frame0, uint32_t nframes,
+                                                  uint32_t n, const double *__restrict__ win) {
+    constexpr int LG = H / 4;
+    constexpr int KB = (64 / H) > 0 ? (64 / H) : 1;
+    constexpr int LDT = H * KB + 4;  // int row stride: 16-byte aligned rows
+    constexpr int LDW = H * KB + 1;  // f64 row stride: odd => lanes (= rows) hit distinct banks
+    __shared__ __attribute__((aligned(16))) int32_t tile[2][AC_MAXROWS * LDT];
+    __shared__ double wt[64 * LDW];
+    switch (threadIdx.x >> 6) {  // wave = lag group; each wave runs its own statically indexed code
+    case 0: ac_wave<H, 0 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
+    case 1: ac_wave<H, 1 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
+    case 2: ac_wave<H, 2 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
+    default: ac_wave<H, 3 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // K4: Levinson-Durbin + order estimate + quantisation, one lane per candidate
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ long long total_key(double x) {  // f64::total_cmp key
@@ -2009,9 +2162,14 @@ template <int H>
 void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                      const double *win, hipStream_t st) {
     uint32_t lanes = nframes * p.ncand;
-    dim3 grid((lanes + 63) / 64, 4);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr<H>), grid, dim3(64), 0, st, p, frame0, nframes, n,
-                       win);
+    if (getenv("FLACGPU_AC_V1")) {
+        dim3 grid((lanes + 63) / 64, 4);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr<H>), grid, dim3(64), 0, st, p, frame0, nframes,
+                           n, win);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
+                           frame0, nframes, n, win);
+    }
 }
 
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
