@@ -1779,6 +1779,7 @@ __device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, 
     }
 }
 
+template <bool FAST>
 __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ uint32_t wave_tot[4];
@@ -1807,6 +1808,15 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     // residual row: every lane reads its own contiguous run straight from HBM/L2 (twice:
     // lengths, then codes; the second pass hits L1/L2)
     const int32_t *__restrict__ r = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
+    int32_t v16[16];  // FAST (n == 4096): this lane's residuals [16 tid, 16 tid + 16) in registers
+    if constexpr (FAST) {
+        const int4 *pr = reinterpret_cast<const int4 *>(r) + 4 * tid;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const int4 t4 = pr[qd];
+            v16[4 * qd] = t4.x; v16[4 * qd + 1] = t4.y; v16[4 * qd + 2] = t4.z; v16[4 * qd + 3] = t4.w;
+        }
+    }
     __syncthreads();
 
     const uint32_t base = prefix_bits;  // bit where the subframe starts inside sb
@@ -1881,7 +1891,23 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
         const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
         // pass 1: code lengths of this lane's residuals (+ partition headers)
         uint32_t mybits = 0;
-        if (lo < hi) {
+        // FAST: a lane's 16-sample run lies inside one partition (partition length % 16 == 0)
+        const uint32_t first16 = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
+        uint32_t fk = 0, feb = 0;
+        bool fhead = false;
+        if constexpr (FAST) {
+            if (first16 < 16) {
+                const uint32_t i0 = 16 * tid + first16;
+                const uint32_t pj = i0 / plen;
+                fk = sp->rice[pj - first_j];
+                feb = sp->escape_bits[pj - first_j];
+                fhead = i0 == (pj * plen > order ? pj * plen : order);
+                if (fhead) mybits += hb + (fk == 0xFF ? 5u : 0u);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if ((uint32_t)e >= first16) mybits += (fk != 0xFF) ? (zigzag(v16[e]) >> fk) + 1u + fk : feb;
+            }
+        } else if (lo < hi) {
             uint32_t pj = lo / plen;                 // partition (block-aligned index)
             uint32_t bound = (pj + 1) * plen;
             uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
@@ -1910,7 +1936,28 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
         uint32_t mypos = pos + v - mybits;
         for (uint32_t w = 0; w < (tid >> 6); w++) mypos += wave_tot[w];
         // pass 2: emit
-        if (lo < hi) {
+        if constexpr (FAST) {
+            if (first16 < 16) {
+                if (fhead) {
+                    if (fk != 0xFF) { lds_put(sb, mypos, fk, hb); mypos += hb; }
+                    else { lds_put(sb, mypos, esc_code, hb); lds_put(sb, mypos + hb, feb, 5); mypos += hb + 5; }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    if ((uint32_t)e >= first16) {
+                        if (fk != 0xFF) {
+                            const uint32_t u = zigzag(v16[e]);
+                            mypos += u >> fk;  // unary zeros (buffer is pre-zeroed)
+                            lds_put(sb, mypos, (1u << fk) | (u & ((1u << fk) - 1u)), fk + 1);
+                            mypos += fk + 1;
+                        } else if (feb) {
+                            lds_put(sb, mypos, (uint32_t)v16[e], feb);
+                            mypos += feb;
+                        }
+                    }
+                }
+            }
+        } else if (lo < hi) {
             uint32_t pj = lo / plen;
             uint32_t bound = (pj + 1) * plen;
             uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
@@ -2263,7 +2310,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)k_pack<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(pack_lds_bytes((uint32_t)B))));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
@@ -2480,8 +2527,18 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
     if (c->timing) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_pack, dim3(p.n_frames * p.channels), dim3(WG), pack_lds_bytes(p.block_size),
-                       st, p, q);
+    {   // frames of exactly 4096 samples take the register fast path
+        const bool fast16 = p.block_size == FN && !getenv("FLACGPU_NO_FAST");
+        const uint32_t n_fast = fast16 ? (p.last_len == p.block_size ? p.n_frames : p.n_frames - 1) : 0;
+        Params pf = p, pg = p;
+        pf.f0 = 0;
+        pf.fcount = n_fast;
+        pg.f0 = n_fast;
+        pg.fcount = p.n_frames - n_fast;
+        const size_t lds = pack_lds_bytes(p.block_size);
+        if (pf.fcount) hipLaunchKernelGGL(k_pack<true>, dim3(pf.fcount * p.channels), dim3(WG), lds, st, pf, q);
+        if (pg.fcount) hipLaunchKernelGGL(k_pack<false>, dim3(pg.fcount * p.channels), dim3(WG), lds, st, pg, q);
+    }
     if (c->timing) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_crc, dim3(p.n_frames), dim3(WG), 0, st, p, q);
     if (c->timing) (void)hipEventRecord(ev[3], st);
