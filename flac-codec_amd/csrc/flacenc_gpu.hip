@@ -1381,7 +1381,7 @@ __global__ void __launch_bounds__(WG) k_fixed16(Params p) {
     for (int e = 0; e < 16; e++)
         res[e] = order == 0 ? x[e] : order == 1 ? d1[e] : order == 2 ? d2[e] : order == 3 ? d3[e] : d4[e];
     uint32_t rbits = 0;
-    const bool fixed_ok = rice16(res, order, p, RS, plan, rbits);
+    const bool fixed_ok = (p.dbg & 1) ? true : rice16(res, order, p, RS, plan, rbits);
     if (tid == 0) {
         plan.reserved[0] = fixed_ok ? 0 : 1;
         plan.type = FLACGPU_SUB_FIXED;
@@ -1498,7 +1498,7 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
             if (tid == 0) atomicAdd(&p.stats[0], 1u);
         } else {
             uint32_t rbits = 0;
-            if (!rice16(res, order, p, RS, plan, rbits)) {
+            if (!(p.dbg & 1) && !rice16(res, order, p, RS, plan, rbits)) {
                 lpc_ok = false;
                 if (tid == 0) atomicAdd(&p.stats[0], 1u);
             }
@@ -2020,10 +2020,33 @@ __device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b) {  // a*b 
 }
 constexpr uint32_t CRC_CHUNK = 16384;  // bytes staged in LDS per pass: 256 lanes x 64 B
 
+constexpr uint32_t gf_mulmod_c(uint32_t a, uint32_t b) {  // compile-time a*b mod P over GF(2)
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; i--) {
+        r = (r & 0x8000) ? ((r << 1) ^ 0x8005) & 0xFFFF : (r << 1) & 0xFFFF;
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+// W[k] = x^(512 k) mod P: weight of a 64-byte slice that is followed by k more slices
+struct CrcWeights {
+    uint16_t w[WG + 1];
+    constexpr CrcWeights() : w() {
+        uint32_t x512 = 0x100;
+        for (int i = 0; i < 6; i++) x512 = gf_mulmod_c(x512, x512);
+        uint32_t v = 1;
+        for (int k = 0; k <= WG; k++) {
+            w[k] = (uint16_t)v;
+            v = gf_mulmod_c(v, x512);
+        }
+    }
+};
+__constant__ CrcWeights kCrcW = CrcWeights();
+
 __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
     __shared__ uint16_t T[4][256];                 // slicing-by-4 tables
     __shared__ uint32_t buf[CRC_CHUNK / 4 + WG];   // one pad dword per 64-byte slice
-    __shared__ uint32_t part[WG];
+    __shared__ uint32_t part[4];
     const uint32_t frame = blockIdx.x, tid = threadIdx.x;
     {
         uint32_t c = tid << 8;
@@ -2035,11 +2058,8 @@ __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(q.out_words);
     const uint64_t begin = q.frame_off[frame];
     const uint32_t len = (uint32_t)(q.frame_off[frame + 1] - begin) - 2;  // all but the CRC itself
-    // x^512 (one 64-byte slice) and x^(8*CRC_CHUNK) mod P
-    uint32_t x512 = 0x100;
-    for (int i = 0; i < 6; i++) x512 = gf_mulmod(x512, x512);
-    uint32_t xchunk = x512;
-    for (int i = 0; i < 8; i++) xchunk = gf_mulmod(xchunk, xchunk);  // (x^512)^256
+    const uint32_t my_weight = kCrcW.w[WG - 1 - tid];   // slices to the right of mine
+    const uint32_t xchunk = kCrcW.w[WG];                // x^(8 * CRC_CHUNK)
     uint32_t running = 0;
     uint32_t pos = 0;
     while (pos < len) {
@@ -2072,15 +2092,13 @@ __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
             crc = T[3][((crc >> 8) ^ v) & 0xFF] ^ T[2][(crc ^ (v >> 8)) & 0xFF] ^
                   T[1][(v >> 16) & 0xFF] ^ T[0][v >> 24];
         }
-        part[tid] = crc;
+        // CRC (init 0) is GF(2)-linear: crc(chunk) = XOR_t crc(slice_t) * x^(512 * slices after t)
+        uint32_t c = gf_mulmod(crc, my_weight);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c ^= __shfl_xor(c, off, 64);
+        if ((tid & 63) == 0) part[tid >> 6] = c;
         __syncthreads();
-        uint32_t shift = x512;
-        for (uint32_t span = 1; span < WG; span <<= 1) {
-            if ((tid & (2 * span - 1)) == 0) part[tid] = gf_mulmod(part[tid], shift) ^ part[tid + span];
-            shift = gf_mulmod(shift, shift);
-            __syncthreads();
-        }
-        running = gf_mulmod(running, xchunk) ^ part[0];
+        running = gf_mulmod(running, xchunk) ^ part[0] ^ part[1] ^ part[2] ^ part[3];
         pos += clen;
     }
     if (tid == 0) {
