@@ -1252,8 +1252,8 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
 // `fast`): lane t of the 256-thread workgroup owns samples [16 t, 16 t + 16) IN REGISTERS;
 // all per-sample loops are statically unrolled, neighbours come through a small LDS halo, no
 // per-block arrays live in LDS (occupancy is register-bound).  Decisions are identical to the
-// generic kernels (same helpers).  Requires candidate bps <= 27 so that 4th-order differences
-// stay inside i32 (the generic kernels handle wider input).
+// generic kernels (same helpers).  Requires candidate bps <= 25 (biased-unsigned difference
+// arithmetic, see k_fixed16); the generic kernels handle wider input.
 // =================================================================================
 __device__ __forceinline__ void load_cand16(const CandSrc &src, uint32_t t, int32_t (&x)[16]) {
     const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 4 * t;
@@ -1294,7 +1294,7 @@ __device__ __forceinline__ void block_sum5(uint64_t (&v)[5], uint64_t *scratch) 
     for (int k = 0; k < 5; k++) v[k] = scratch[k] + scratch[5 + k] + scratch[10 + k] + scratch[15 + k];
 }
 
-__global__ void __launch_bounds__(WG) k_fixed16(Params p) {
+__global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
     __shared__ RiceShared RS;
     __shared__ SubPlan plan;
     __shared__ uint64_t red[20];
@@ -1353,24 +1353,33 @@ __global__ void __launch_bounds__(WG) k_fixed16(Params p) {
 #pragma unroll
         for (int e = 0; e < 16; e++) q[4 + e] = x[e];
     }
-    // residuals of orders 1..4 (i32 exact: |x| < 2^26) and abs sums over [4, n), encode.rs:3039-3073
-    int32_t d1[16], d2[16], d3[16], d4[16];
-    uint64_t sm[5] = {0, 0, 0, 0, 0};
+    // residuals of orders 1..4 by iterated first differences (encode.rs:3039-3060) and their
+    // abs sums over [4, n) (:3062-3073).  Candidates here are <= 25 bits wide, so |d4| < 2^28:
+    // values are kept biased by 2^30 as unsigned, |a - b| + acc is one v_sad_u32, and two u32
+    // accumulators per order (8 terms each) cannot overflow.
+    constexpr uint32_t BIAS = 1u << 30;
+    uint32_t b0[20], b1[19], b2[18], b3[17];
+#pragma unroll
+    for (int i = 0; i < 20; i++) b0[i] = (uint32_t)q[i] + BIAS;
+#pragma unroll
+    for (int i = 0; i < 19; i++) b1[i] = b0[i + 1] - b0[i] + BIAS;   // d1 at sample 16t-3+i
+#pragma unroll
+    for (int i = 0; i < 18; i++) b2[i] = b1[i + 1] - b1[i] + BIAS;   // d2 at sample 16t-2+i
+#pragma unroll
+    for (int i = 0; i < 17; i++) b3[i] = b2[i + 1] - b2[i] + BIAS;   // d3 at sample 16t-1+i
+    uint32_t a0[2] = {0, 0}, a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0}, a4[2] = {0, 0};
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const int32_t x0 = q[e + 4], x1 = q[e + 3], x2 = q[e + 2], x3 = q[e + 1], x4 = q[e];
-        d1[e] = x0 - x1;
-        d2[e] = x0 - 2 * x1 + x2;
-        d3[e] = x0 - 3 * x1 + 3 * x2 - x3;
-        d4[e] = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
         if (tid > 0 || e >= 4) {
-            sm[0] += uabs(x0);
-            sm[1] += uabs(d1[e]);
-            sm[2] += uabs(d2[e]);
-            sm[3] += uabs(d3[e]);
-            sm[4] += uabs(d4[e]);
+            a0[e & 1] = __usad(b0[e + 4], BIAS, a0[e & 1]);
+            a1[e & 1] = __usad(b0[e + 4], b0[e + 3], a1[e & 1]);
+            a2[e & 1] = __usad(b1[e + 3], b1[e + 2], a2[e & 1]);
+            a3[e & 1] = __usad(b2[e + 2], b2[e + 1], a3[e & 1]);
+            a4[e & 1] = __usad(b3[e + 1], b3[e], a4[e & 1]);
         }
     }
+    uint64_t sm[5] = {(uint64_t)a0[0] + a0[1], (uint64_t)a1[0] + a1[1], (uint64_t)a2[0] + a2[1],
+                      (uint64_t)a3[0] + a3[1], (uint64_t)a4[0] + a4[1]};
     block_sum5(sm, red);
     uint32_t order = 0;
 #pragma unroll
@@ -1379,7 +1388,11 @@ __global__ void __launch_bounds__(WG) k_fixed16(Params p) {
     int32_t res[16];
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        res[e] = order == 0 ? x[e] : order == 1 ? d1[e] : order == 2 ? d2[e] : order == 3 ? d3[e] : d4[e];
+        res[e] = order == 0 ? (int32_t)(b0[e + 4] - BIAS)
+               : order == 1 ? (int32_t)(b1[e + 3] - BIAS)
+               : order == 2 ? (int32_t)(b2[e + 2] - BIAS)
+               : order == 3 ? (int32_t)(b3[e + 1] - BIAS)
+                            : (int32_t)(b3[e + 1] - b3[e]);
     uint32_t rbits = 0;
     const bool fixed_ok = (p.dbg & 1) ? true : rice16(res, order, p, RS, plan, rbits);
     if (tid == 0) {
@@ -1408,11 +1421,12 @@ __global__ void __launch_bounds__(WG) k_fixed16(Params p) {
     }
 }
 
-// FIR over a register window: pw[0..31] = the 32 samples before this lane's run, pw[32..47] its
-// own 16 samples; T taps (order rounded up to 4, missing coefficients are zero)
-template <int T>
-__device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[48], const int32_t *qlp /* LDS */,
+// FIR over a register window: the PW-16 samples before this lane's run followed by its own 16
+// samples; T taps (order rounded up to 4, missing coefficients are zero)
+template <int T, int PW>
+__device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[PW], const int32_t *qlp /* LDS */,
                                           uint32_t shift, uint32_t first, int32_t (&res)[16]) {
+    constexpr int O = PW - 16;  // index of this lane's first own sample in the window
     int32_t c[T];
 #pragma unroll
     for (int j = 0; j < T; j++) c[j] = qlp[j];
@@ -1421,15 +1435,17 @@ __device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[48], const int32_t
     for (int e = 0; e < 16; e++) {
         long long sum = 0;
 #pragma unroll
-        for (int j = 0; j < T; j++) sum += (long long)pw[32 + e - 1 - j] * (long long)c[j];
+        for (int j = 0; j < T; j++) sum += (long long)pw[O + e - 1 - j] * (long long)c[j];
         const int32_t pred = (int32_t)(sum >> shift);
-        const long long d = (long long)pw[32 + e] - (long long)pred;
+        const long long d = (long long)pw[O + e] - (long long)pred;
         if ((uint32_t)e >= first && (d < INT32_MIN || d > INT32_MAX)) ovf = 1;  // ResidualOverflow
         res[e] = (int32_t)d;
     }
     return ovf;
 }
 
+// PREV = rows of 16 earlier samples a lane needs: 1 when every order <= 16, else 2
+template <int PREV>
 __global__ void __launch_bounds__(WG) k_fir16(Params p) {
     __shared__ RiceShared RS;
     __shared__ SubPlan plan;
@@ -1454,14 +1470,15 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
     if (lpc_ok) {
         const uint32_t order = lp->order, shift = lp->shift;
         if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = tid < order ? lp->qlp[tid] : 0;
-        int32_t pw[48];
+        constexpr int PW = 16 * PREV + 16;
+        int32_t pw[PW];
         {
             int32_t x[16];
             load_cand16(src, tid, x);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 x[e] >>= wasted;
-                pw[32 + e] = x[e];
+                pw[16 * PREV + e] = x[e];
             }
             int4 *row = reinterpret_cast<int4 *>(xs + tid * 20);
 #pragma unroll
@@ -1469,8 +1486,8 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {  // rows tid-2, tid-1
-            const int srcrow = (int)tid - 2 + rr;
+        for (int rr = 0; rr < PREV; rr++) {  // rows tid-PREV .. tid-1
+            const int srcrow = (int)tid - PREV + rr;
             const int4 *row = reinterpret_cast<const int4 *>(xs + (srcrow < 0 ? 0 : srcrow) * 20);
 #pragma unroll
             for (int qd = 0; qd < 4; qd++) {
@@ -1482,15 +1499,24 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
         const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
         int32_t res[16];
         uint32_t ovf;
-        switch ((order + 3) >> 2) {  // encode_residuals, encode.rs:3181-3197
-        case 1: ovf = fir16<4>(pw, qlp, shift, first, res); break;
-        case 2: ovf = fir16<8>(pw, qlp, shift, first, res); break;
-        case 3: ovf = fir16<12>(pw, qlp, shift, first, res); break;
-        case 4: ovf = fir16<16>(pw, qlp, shift, first, res); break;
-        case 5: ovf = fir16<20>(pw, qlp, shift, first, res); break;
-        case 6: ovf = fir16<24>(pw, qlp, shift, first, res); break;
-        case 7: ovf = fir16<28>(pw, qlp, shift, first, res); break;
-        default: ovf = fir16<32>(pw, qlp, shift, first, res); break;
+        if constexpr (PREV == 1) {
+            switch ((order + 3) >> 2) {  // encode_residuals, encode.rs:3181-3197
+            case 1: ovf = fir16<4, PW>(pw, qlp, shift, first, res); break;
+            case 2: ovf = fir16<8, PW>(pw, qlp, shift, first, res); break;
+            case 3: ovf = fir16<12, PW>(pw, qlp, shift, first, res); break;
+            default: ovf = fir16<16, PW>(pw, qlp, shift, first, res); break;
+            }
+        } else {
+            switch ((order + 3) >> 2) {
+            case 1: ovf = fir16<4, PW>(pw, qlp, shift, first, res); break;
+            case 2: ovf = fir16<8, PW>(pw, qlp, shift, first, res); break;
+            case 3: ovf = fir16<12, PW>(pw, qlp, shift, first, res); break;
+            case 4: ovf = fir16<16, PW>(pw, qlp, shift, first, res); break;
+            case 5: ovf = fir16<20, PW>(pw, qlp, shift, first, res); break;
+            case 6: ovf = fir16<24, PW>(pw, qlp, shift, first, res); break;
+            case 7: ovf = fir16<28, PW>(pw, qlp, shift, first, res); break;
+            default: ovf = fir16<32, PW>(pw, qlp, shift, first, res); break;
+            }
         }
         ovf = block_or_u32(ovf, red);
         if (ovf) {
@@ -2448,7 +2474,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     begin(2);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
     // block sizes, a short last frame, candidates wider than 27 bits) the generic LDS ones
-    const bool fast16 = (B == FN) && (c->bps + (c->stereo4 ? 1u : 0u) <= 27u) && !getenv("FLACGPU_NO_FAST");
+    const bool fast16 = (B == FN) && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
     const uint32_t n_fast = fast16 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
     Params pf = p, pg = p;
     pf.f0 = 0;
@@ -2466,7 +2492,12 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         begin(4);
         hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
         begin(5);
-        if (pf.fcount) hipLaunchKernelGGL(k_fir16, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
+        if (pf.fcount) {
+            if (p.max_lpc_order <= 16)
+                hipLaunchKernelGGL(k_fir16<1>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
+            else
+                hipLaunchKernelGGL(k_fir16<2>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
+        }
         if (pg.fcount) hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
     begin(6);
