@@ -240,63 +240,75 @@ __device__ __forceinline__ void rice_init(RiceShared &S) {
 __device__ __forceinline__ void rice_tree(RiceShared &S, uint32_t n, uint32_t order, uint32_t P,
                                           uint32_t rice_max) {
     const uint32_t tid = threadIdx.x;
-    if (tid < 64) {  // exclusive prefix of the 64 leaf sums (one wave)
-        unsigned long long incl = S.leaf[tid];
+    // heap numbering: node = 2^level + j.  Nodes 1..63 (levels 0..5) are lanes of wave 0, which
+    // first builds the inclusive prefix of the leaf sums with shuffles (no barrier) and reads
+    // partition sums as prefix differences; nodes 64..127 exist only for P == 6 and are the
+    // leaves themselves (wave 1).
+    if (tid < 128) {
+        unsigned long long incl = 0;
+        if (tid < 64) {
+            incl = S.leaf[tid];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned long long t = __shfl_up(incl, off, 64);
-            if (tid >= (uint32_t)off) incl += t;
+            for (int off = 1; off < 64; off <<= 1) {
+                unsigned long long t = __shfl_up(incl, off, 64);
+                if (tid >= (uint32_t)off) incl += t;
+            }
         }
-        S.pre[tid + 1] = incl;
-        if (tid == 0) S.pre[0] = 0;
-    }
-    __syncthreads();
-    // heap numbering: node = 2^level + j
-    if (tid >= 1 && tid < (2u << P)) {
         const uint32_t node = tid;
-        const uint32_t lvl = 31u - (uint32_t)__builtin_clz(node);
+        const bool is_node = node >= 1 && node < (2u << P);
+        const uint32_t lvl = is_node ? 31u - (uint32_t)__builtin_clz(node) : 0u;
         const uint32_t j = node - (1u << lvl);
-        const uint32_t plen = n >> lvl;
-        const uint32_t start = j * plen, end = start + plen;
-        const uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
-        const uint32_t span = 1u << (P - lvl);
-        const unsigned long long sum = S.pre[(j + 1) * span] - S.pre[j * span];
-        uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0;
-        uint32_t est = 0, bad = 0;
-        if (cnt > 0 && sum > 0) {
-            uint32_t k = 0;
-            bool standard = true;
-            if (sum > (unsigned long long)cnt) {
-                const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
-                const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
-                k = bs > bc ? bs - bc - 1 : 0;
-                while (((unsigned long long)cnt << k) < sum) k++;
-                if (k >= rice_max) {
-                    standard = false;
-                    const uint32_t e = (bs - 1) + 2u;  // ilog2(sum) + 2
-                    if (e > 31u) bad = 1;
-                    kind = PK_ESCAPED;
-                    esc = (uint8_t)e;
-                    est = e * cnt;
+        unsigned long long sum;
+        if (tid < 64) {
+            const uint32_t span = 1u << (P - (lvl <= P ? lvl : P));
+            const uint32_t hi = (j + 1) * span - 1, lo = j * span;  // leaves [lo, hi]
+            const unsigned long long top = __shfl(incl, (int)(hi & 63), 64);
+            const unsigned long long bot = __shfl(incl, (int)((lo ? lo - 1 : 0) & 63), 64);
+            sum = top - (lo ? bot : 0ull);
+        } else {
+            sum = S.leaf[node & 63];
+        }
+        if (is_node) {
+            const uint32_t plen = n >> lvl;
+            const uint32_t start = j * plen, end = start + plen;
+            const uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
+            uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0;
+            uint32_t est = 0, bad = 0;
+            if (cnt > 0 && sum > 0) {
+                uint32_t k = 0;
+                bool standard = true;
+                if (sum > (unsigned long long)cnt) {
+                    const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
+                    const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
+                    k = bs > bc ? bs - bc - 1 : 0;
+                    while (((unsigned long long)cnt << k) < sum) k++;
+                    if (k >= rice_max) {
+                        standard = false;
+                        const uint32_t e = (bs - 1) + 2u;  // ilog2(sum) + 2
+                        if (e > 31u) bad = 1;
+                        kind = PK_ESCAPED;
+                        esc = (uint8_t)e;
+                        est = e * cnt;
+                    }
+                }
+                if (standard) {
+                    const unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
+                    if (t > 0xFFFFFFFFull) bad = 1;  // u32::try_from fails -> candidate dropped
+                    kind = PK_STANDARD;
+                    rice = (uint8_t)k;
+                    est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
                 }
             }
-            if (standard) {
-                const unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
-                if (t > 0xFFFFFFFFull) bad = 1;  // u32::try_from fails -> candidate dropped
-                kind = PK_STANDARD;
-                rice = (uint8_t)k;
-                est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
+            S.nd_kind[node] = kind;
+            S.nd_rice[node] = rice;
+            S.nd_esc[node] = esc;
+            S.nd_cnt[node] = cnt;
+            if (cnt > 0) {  // chunks lying inside the warm-up are not partitions
+                atomicAdd(&S.lv_est[lvl], est);
+                atomicAdd(&S.lv_count[lvl], 1u);
+                if (bad) atomicOr(&S.lv_bad[lvl], 1u);
+                if (kind == PK_STANDARD && rice >= 15) atomicOr(&S.lv_hi[lvl], 1u);
             }
-        }
-        S.nd_kind[node] = kind;
-        S.nd_rice[node] = rice;
-        S.nd_esc[node] = esc;
-        S.nd_cnt[node] = cnt;
-        if (cnt > 0) {  // chunks lying inside the warm-up are not partitions
-            atomicAdd(&S.lv_est[lvl], est);
-            atomicAdd(&S.lv_count[lvl], 1u);
-            if (bad) atomicOr(&S.lv_bad[lvl], 1u);
-            if (kind == PK_STANDARD && rice >= 15) atomicOr(&S.lv_hi[lvl], 1u);
         }
     }
     __syncthreads();
@@ -428,12 +440,12 @@ __device__ bool rice16(const int32_t (&v)[16], uint32_t order, const Params &p, 
     const uint32_t tid = threadIdx.x;
     const uint32_t P = rice_levels(FN, p);
     const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
-    rice_init(S);
+    // precondition: rice_init(S) was called and a barrier passed since (the kernels do it
+    // ahead of their first workgroup reduction)
     unsigned long long acc = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++)
         if ((uint32_t)e >= first) acc += uabs(v[e]);
-    __syncthreads();
     atomicAdd(&S.leaf[(16 * tid) >> (12 - P)], acc);  // leaf length = 4096 >> P >= 64
     __syncthreads();
     rice_tree(S, FN, order, P, p.use_rice2 ? 31u : 15u);
@@ -1322,6 +1334,7 @@ __global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
     uint32_t orv = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++) orv |= (uint32_t)x[e];
+    rice_init(RS);
     orv = block_or_u32(orv, red);
     plan_clear(plan);
     const uint32_t wasted = orv ? (uint32_t)__builtin_ctz(orv) : 32u;  // encode.rs:2878-2898
@@ -1518,6 +1531,7 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
             default: ovf = fir16<32, PW>(pw, qlp, shift, first, res); break;
             }
         }
+        rice_init(RS);
         ovf = block_or_u32(ovf, red);
         if (ovf) {
             lpc_ok = false;
