@@ -163,9 +163,23 @@ def main():
         hbm_kernels = {k: v for k, v in kernels.items() if "GB/s" in v}
         dom = max(hbm_kernels, key=lambda k: hbm_kernels[k]["ms"])
         achieved = hbm_kernels[dom]["GB/s"]
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same
+        # command, tools/collect_profiles.sh; corrected as MI355X_MICROARCH.md prescribes)
+        traffic = None
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+            if prof and F == FRAMES:
+                t = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                fast = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr2",
+                        "k_deinterleave": "k_deinterleave2"}
+                key = fast.get(dom, dom) if fast.get(dom, dom) in t else dom
+                if key in t:
+                    traffic = {"bytes": t[key]["hbm_bytes"], "source": prof[-1], "kernel": key}
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
-                    "avg_launch_ms": hbm_kernels[dom]["ms"]}
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
 
         # ---- CPU baseline: the oracle (C restatement of the reference, NOT the Rust binary),
         # timed on this box's host cores over the same workload

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun).  Collects for the bench command:
+#   1. rocprofv3 --kernel-trace --stats            -> gpurun_out/<tag>/stats
+#   2. rocprofv3 --pmc FETCH_SIZE                  -> gpurun_out/<tag>/fetch   (separate pass)
+#   3. rocprofv3 --pmc WRITE_SIZE                  -> gpurun_out/<tag>/write   (separate pass)
+# (counter passes never combine with trace domains other than kernel-trace; see MI355X guide)
+set -e
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+cd $ROOT && python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+ls -R $OUT | head -30
