@@ -2308,7 +2308,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     // Options validation, encode.rs:1418-1455; stream validation, :495, :1904
     if (o->block_size < 16 || o->block_size > 65535 || o->max_lpc_order > 32 ||
         o->max_partition_order > 15 || bps < 1 || bps > 32 || channels < 1 || channels > 8 ||
-        max_frames == 0) {
+        max_frames == 0 || max_frames > 65535) {  // frames index gridDim.y of K0
         g_last_error = "invalid option / stream parameter";
         return FLACGPU_ERR_INVALID_ARG;
     }

@@ -1,0 +1,95 @@
+"""Full-size checks (BASELINE.json configs at their real sizes) through size-independent
+properties: encode -> decode round trip with MD5, CRC-8/16 on every frame, byte identity on
+sampled frames, idempotence across batch sizes."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for
+from _pcm import generate_sine_2, synth_fast
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tiled(seed, ch, bps, frames, block=4096, distinct=256):
+    base = synth_fast(seed, ch, bps, block * min(distinct, frames))
+    # vary each repetition a little so frames are not identical
+    reps = (frames + distinct - 1) // distinct
+    parts = []
+    for r in range(reps):
+        parts.append(((base.astype(np.int64) + (r & 3)) .clip(-(1 << (bps - 1)), (1 << (bps - 1)) - 1)).astype(np.int32))
+    return np.concatenate(parts)[: frames * block * ch]
+
+
+@pytest.mark.parametrize("ch,bps,rate,frames,lpc", [
+    (2, 24, 48000, 8192, 12),    # config 3 (headline) at full size
+    (2, 16, 48000, 8192, 0),     # config 2 (fixed predictors only)
+    (8, 24, 192000, 2048, 12),   # config 4 shape (per-GPU share)
+    (2, 24, 96000, 2048, 32),    # config 5 (order 32)
+])
+def test_full_size_roundtrip(ch, bps, rate, frames, lpc):
+    from flac_codec_amd.encode import FlacSampleWriter, Options
+
+    pcm = tiled(300 + ch + bps + lpc, ch, bps, frames)
+    opts = Options.best().batch_frames(min(frames, 4096))
+    opts.max_lpc_order(lpc if lpc else None)
+    if lpc == 0:
+        opts.max_partition_order(5)
+    w = FlacSampleWriter(None, opts, rate, bps, ch, pcm.size)
+    step = 4096 * ch * 1000 + 12345 * ch
+    for s in range(0, pcm.size, step):
+        w.write(pcm[s:s + step])
+    w.finalize()
+    data = w.getvalue()
+    st = w.stats()
+    w.close()
+    rc, out, info = orc.decode_stream(data)   # verifies CRC-8 / CRC-16 of every frame + MD5
+    assert rc == 0 and info.md5_ok == 1
+    assert info.frames == frames == st.frames
+    assert np.array_equal(out, pcm)
+    assert (info.min_frame, info.max_frame) == (st.min_frame_size, st.max_frame_size)
+    # byte identity with the oracle on a sample of frames spread over the stream
+    oo = orc_options_for(4096, opts._c.max_partition_order, lpc, True, True)
+    # locate frames by re-encoding sampled blocks with the oracle and searching the stream
+    for f in (0, 1, frames // 2, frames - 1):
+        blk = pcm[f * 4096 * ch:(f + 1) * 4096 * ch].reshape(4096, ch).T
+        rc, fb, _ = orc.encode_frame(oo, rate, bps, np.ascontiguousarray(blk), frame_number=f)
+        assert rc == 0 and fb in data, f"frame {f} not byte-identical to the oracle"
+
+
+def test_batch_size_independence():
+    """The same stream encoded with different GPU batch sizes gives identical bytes."""
+    from flac_codec_amd.encode import FlacSampleWriter, Options
+
+    pcm = synth_fast(400, 2, 24, 4096 * 37 + 55)
+    outs = []
+    for bf in (1, 7, 64):
+        w = FlacSampleWriter(None, Options.best().batch_frames(bf), 48000, 24, 2, pcm.size)
+        w.write(pcm)
+        w.finalize()
+        outs.append(w.getvalue())
+        w.close()
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_wav2flac_example(tmp_path):  # BASELINE config 1: 10 s 44.1 kHz/16-bit stereo sine WAV
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import wav2flac
+
+    pcm = generate_sine_2(32767.0, 44100.0, 441000, 441.0, 0.5, 441.0, 0.0, 1.0)
+    raw = pcm.astype("<i2").tobytes()
+    wav = tmp_path / "sine.wav"
+    with open(wav, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16))
+        f.write(b"data" + struct.pack("<I", len(raw)) + raw)
+    out = tmp_path / "sine.flac"
+    wav2flac.convert_wav(str(wav), str(out))
+    data = open(out, "rb").read()
+    rc, ref, _ = orc.encode_stream(orc.options("default"), 44100, 16, 2, pcm, total_known=True)
+    assert rc == 0 and data == ref
