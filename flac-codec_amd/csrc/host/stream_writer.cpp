@@ -5,6 +5,7 @@
 // metadata.  C ABI: include/flacenc_stream.h.
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -261,6 +262,7 @@ struct flacenc_writer {
     std::vector<flacgpu_subframe_plan> subs;
     std::vector<int32_t> rows;
     std::vector<uint8_t> md5_bytes;
+    std::vector<uint8_t> outbuf;  // frames fetched from the device
     flacenc_stats stats{};
 
     ~flacenc_writer() {
@@ -368,6 +370,7 @@ struct flacenc_writer {
             const uint32_t ll = (usable == n_frames) ? last_len : B;
             if (frame_number + usable - 1 > kMaxFrameNumber) return FLACENC_ERR_EXCESSIVE_FRAME_NUMBER;
             PackedBatch pb;
+            size_t dev_total = 0;
             double t0 = now_ms();
             if (o.host_pack) {
                 int rc = flacgpu_analyze(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
@@ -382,15 +385,16 @@ struct flacenc_writer {
             } else {
                 // frames assembled on the device: only the finished bytes cross PCIe
                 std::vector<uint64_t> off(usable + 1);
-                pb.bytes.resize((static_cast<size_t>(usable - 1) * B + ll) * C * 4 + usable * 128 + 1024);
+                const size_t need = (static_cast<size_t>(usable - 1) * B + ll) * C * 4 + usable * 128 + 1024;
+                if (outbuf.size() < need) outbuf.resize(need);  // grown once, reused by every batch
                 uint64_t total = 0;
                 int rc = flacgpu_encode_frames(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
-                                               frame_number, si.sample_rate, pb.bytes.data(),
-                                               pb.bytes.size(), off.data(), &total);
+                                               frame_number, si.sample_rate, outbuf.data(),
+                                               outbuf.size(), off.data(), &total);
                 stats.gpu_ms += now_ms() - t0;
                 if (rc) return map_gpu_error(rc);
-                pb.bytes.resize(total);
                 pb.offsets.assign(off.begin(), off.end());
+                dev_total = total;
             }
             for (uint32_t f = 0; f < usable; f++) {
                 const uint32_t n = (f + 1 == usable) ? ll : B;
@@ -403,8 +407,10 @@ struct flacenc_writer {
                 }
             }
             frame_number += usable;
-            byte_count += pb.bytes.size();
-            if (int e = sink.write(pb.bytes.data(), pb.bytes.size())) return e;
+            const uint8_t *obytes = o.host_pack ? pb.bytes.data() : outbuf.data();
+            const size_t olen = o.host_pack ? pb.bytes.size() : dev_total;
+            byte_count += olen;
+            if (int e = sink.write(obytes, olen)) return e;
         }
         if (deferred) {
             // the reference pushes the seekpoint and bumps samples_written before failing
@@ -419,16 +425,24 @@ struct flacenc_writer {
         const size_t frame_samples = static_cast<size_t>(o.block_size) * si.channels;
         size_t consumed = 0;
         int rc = 0;
-        while (rc == 0) {
-            size_t whole = (backlog.size() - consumed) / frame_samples;
-            if (whole == 0) break;
-            if (!final_flush && whole < batch_frames) break;  // wait for a full batch
+        // blocks this call will cut: whole batches, or everything at the final flush
+        size_t whole_all = backlog.size() / frame_samples;
+        if (!final_flush) whole_all -= whole_all % batch_frames;
+        // The stream MD5 is one serial chain over the PCM (encode.rs:571): it runs on its own
+        // host thread over the samples of this call while the GPU batches are in flight
+        std::future<void> md5_job;
+        if (whole_all)
+            md5_job = std::async(std::launch::async, [this, n = whole_all * frame_samples]() {
+                md5_samples(backlog.data(), n);
+            });
+        while (rc == 0 && consumed < whole_all * frame_samples) {
+            size_t whole = whole_all - consumed / frame_samples;
             uint32_t take = static_cast<uint32_t>(std::min<size_t>(whole, batch_frames));
             const int32_t *src = backlog.data() + consumed;
-            md5_samples(src, take * frame_samples);
             rc = encode_blocks(src, take, o.block_size);
             consumed += take * frame_samples;
         }
+        if (md5_job.valid()) md5_job.get();
         if (consumed) backlog.erase(backlog.begin(), backlog.begin() + static_cast<ptrdiff_t>(consumed));
         return rc;
     }
