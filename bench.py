@@ -138,6 +138,17 @@ def main():
             for k, v in {**ms_a, **ms_b}.items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         an.set_timing(False)
+        # experiment: the same autocorrelation on the f64 matrix cores (NOT bit-exact, not used)
+        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+        mf = an.experiment_mfma_autocorr()
+        issued = 4 * F * (BLOCK // 64) * 2 * 2048.0       # MFMAs x 2048 flop (16x16x4 f64)
+        mfma_exp = {"kernel": "k_autocorr_mfma", "ms": round(mf["ms"], 4),
+                    "issued_TFLOP/s": round(issued / (mf["ms"] * 1e-3) / 1e12, 2),
+                    "mfma_util_vs_78.6_TF": round(issued / (mf["ms"] * 1e-3) / 78.6e12, 4),
+                    "max_rel_err_of_a_lag": mf["max_rel_err"],
+                    "candidates_compared": mf["compared"],
+                    "candidates_whose_quantised_lpc_params_change": mf["params_differ"],
+                    "note": "re-associated sums are not the reference's left fold; kept off the product path"}
         n_cand = 4 * F                      # L, R, M, S per stereo frame
         cand_samples = n_cand * BLOCK
         # algorithmic bytes / flops per launch (DESIGN.md "Kernels")
@@ -226,6 +237,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "mfma_autocorr_experiment": mfma_exp,
             "compression_ratio": round(compressed_bytes / (F * BLOCK * CHANNELS * 3), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
             "parity_checked_frames": check,

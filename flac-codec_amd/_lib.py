@@ -112,6 +112,8 @@ def lib():
     L.flacenc_pack_frames.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, ip, C.c_uint32,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.flacgpu_experiment_mfma_autocorr.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                                   C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]
     L.flacgpu_kernel_name.restype = C.c_char_p
     _lib = L

@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -1005,6 +1007,64 @@ __global__ void __launch_bounds__(WG) k_autocorr2(Params p, uint32_t frame0, uin
     case 2: ac_wave<H, 2 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
     default: ac_wave<H, 3 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// EXPERIMENT (not on the product path): autocorrelation on the f64 matrix cores.
+// Block-Gram form: with X[a][m] = w[16 a + m] (a = 0..n/16-1, m = 0..15),
+//   G1 = X^T X            (pairs inside one 16-sample block)
+//   G2[m][m'] = sum_a X[a][m] X[a+1][m']   (pairs straddling two consecutive blocks)
+//   ac[lag] = sum_{m'-m=lag} G1[m][m'] + sum_{m'+16-m=lag} G2[m][m'],   0 <= lag <= 16.
+// One wave per candidate; per 64 samples two v_mfma_f64_16x16x4_f64 (lane l feeds
+// A[l&15][l>>4] = B[l>>4][l&15] = w[64 s + l] for G1, B = w[64 s + 16 + l] for G2).
+// The summation order differs from the reference's left fold, so the result is NOT
+// bit-exact; flacgpu_experiment_mfma_autocorr() measures both its speed and how many
+// candidates' quantised LPC parameters change.  On MI355X the f64 MFMA peak equals the f64
+// VALU peak, so this buys no time either.
+// ---------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(WG) k_autocorr_mfma(Params p, uint32_t n,
+                                                      const double *__restrict__ win,
+                                                      double *__restrict__ ac_out) {
+    __shared__ double acc[4][20];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t total = p.n_frames * p.ncand;
+    const uint32_t cidx = blockIdx.x * 4 + wave;
+    const bool live = cidx < total;
+    const uint32_t cc = live ? cidx : 0;
+    const uint32_t frame = cc / p.ncand, cand = cc % p.ncand;
+    const CandSrc src = cand_src(p, frame, cand);
+    const CandInfo ci = p.cinfo[cc];
+    const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
+    if (lane < 20) acc[wave][lane] = 0.0;
+    auto load = [&](uint32_t s) -> double {
+        const uint32_t i = 64 * s + lane;
+        if (i >= n) return 0.0;
+        return (double)(combine(src.mode, src.a[i], src.b[i]) >> wasted) * win[i];
+    };
+    double4_t g1 = {0, 0, 0, 0}, g2 = {0, 0, 0, 0};
+    const uint32_t nsteps = (n + 63) / 64;
+    double cur = load(0);
+    for (uint32_t s = 0; s < nsteps; s++) {
+        const double nxt = (s + 1 < nsteps) ? load(s + 1) : 0.0;
+        const double from_cur = __shfl(cur, (int)((lane + 16) & 63), 64);
+        const double from_nxt = __shfl(nxt, (int)((lane + 16) & 63), 64);
+        const double wb = lane < 48 ? from_cur : from_nxt;
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur, cur, g1, 0, 0, 0);
+        g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur, wb, g2, 0, 0, 0);
+        cur = nxt;
+    }
+    __syncthreads();
+    // lane l holds D[row = (l >> 4) + 4 r][col = l & 15] (f64 C/D layout)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = (int)(lane >> 4) + 4 * r, j = (int)(lane & 15);
+        if (j - i >= 0) atomicAdd(&acc[wave][j - i], g1[r]);
+        if (j + 16 - i <= 16) atomicAdd(&acc[wave][j + 16 - i], g2[r]);
+    }
+    __syncthreads();
+    if (live && lane <= 16) ac_out[(size_t)cc * AC_LD + lane] = acc[wave][lane];
 }
 
 // ---------------------------------------------------------------------------------
@@ -2659,6 +2719,59 @@ int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32
     rc = flacgpu_pack_device(c, first_frame_number, sample_rate, c->own_stream);
     if (rc) return rc;
     return flacgpu_fetch_frames(c, out, cap, offsets, total);
+}
+
+int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t *compared,
+                                     uint32_t *params_differ, double *max_rel_err) {
+    if (!c || c->last_frames == 0 || c->opts.max_lpc_order == 0 || c->opts.max_lpc_order > 16 ||
+        c->last_len != c->opts.block_size) {
+        g_last_error = "mfma experiment: needs an analysed batch of full blocks with 1 <= max_lpc_order <= 16";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    hipStream_t st = c->own_stream;
+    Params p = c->last_params;
+    const size_t nc = (size_t)p.n_frames * p.ncand;
+    std::vector<LpcParams> exact(nc), mfma(nc);
+    std::vector<double> ac_exact(nc * AC_LD), ac_mfma(nc * AC_LD);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(exact.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ac_exact.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost));
+    // warm-up + timed launch of the MFMA kernel, writing into the regular ac buffer
+    for (int it = 0; it < 2; it++) {
+        if (it == 1) (void)hipEventRecord(c->ev[0], st);
+        hipLaunchKernelGGL(k_autocorr_mfma, dim3((unsigned)((nc + 3) / 4)), dim3(WG), 0, st, p,
+                           p.block_size, c->d_window_full, c->d_ac);
+        if (it == 1) (void)hipEventRecord(c->ev[1], st);
+    }
+    hipLaunchKernelGGL(k_lpc, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, p);
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    HIP_TRY(hipMemcpy(mfma.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ac_mfma.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost));
+    // restore the exact results so that the context stays consistent
+    HIP_TRY(hipMemcpy(c->d_lpc, exact.data(), sizeof(LpcParams) * nc, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ac, ac_exact.data(), sizeof(double) * nc * AC_LD, hipMemcpyHostToDevice));
+    uint32_t cmp = 0, diff = 0;
+    double worst = 0.0;
+    for (size_t i = 0; i < nc; i++) {
+        if (exact[i].status != 0 && mfma[i].status != 0) continue;
+        cmp++;
+        bool d = exact[i].status != mfma[i].status || exact[i].order != mfma[i].order ||
+                 exact[i].shift != mfma[i].shift;
+        if (!d)
+            for (uint32_t j = 0; j < exact[i].order; j++) d |= exact[i].qlp[j] != mfma[i].qlp[j];
+        diff += d;
+        for (uint32_t l = 0; l <= c->opts.max_lpc_order; l++) {
+            double e = ac_exact[i * AC_LD + l], m = ac_mfma[i * AC_LD + l];
+            if (e != 0.0) worst = std::max(worst, std::abs((m - e) / e));
+        }
+    }
+    if (kernel_ms) *kernel_ms = ms;
+    if (compared) *compared = cmp;
+    if (params_differ) *params_differ = diff;
+    if (max_rel_err) *max_rel_err = worst;
+    return FLACGPU_OK;
 }
 
 int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {

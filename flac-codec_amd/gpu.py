@@ -114,6 +114,17 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_encode_frames")
         return buf[: total.value].tobytes(), list(off)
 
+    def experiment_mfma_autocorr(self):
+        """EXPERIMENT (not on the product path): f64-MFMA autocorrelation of the last batch.
+        Returns dict(ms, compared, params_differ, max_rel_err)."""
+        ms, cmp_, diff, err = C.c_float(0), C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+        rc = _lib.lib().flacgpu_experiment_mfma_autocorr(self._h, C.byref(ms), C.byref(cmp_),
+                                                         C.byref(diff), C.byref(err))
+        if rc:
+            raise GpuError(rc, "flacgpu_experiment_mfma_autocorr")
+        return {"ms": ms.value, "compared": cmp_.value, "params_differ": diff.value,
+                "max_rel_err": err.value}
+
     def stats(self):
         s = GpuStats()
         rc = _lib.lib().flacgpu_get_stats(self._h, C.byref(s))

@@ -186,6 +186,15 @@ int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint
                           uint32_t sample_rate, uint8_t *out, size_t cap, uint64_t *offsets,
                           uint64_t *total);
 
+/* EXPERIMENT, not on the product path: recomputes the autocorrelation of the last analysed
+ * batch on the f64 matrix cores (v_mfma_f64_16x16x4_f64, block-Gram form), times that kernel,
+ * reruns Levinson/quantisation on it and reports how many candidates' quantised LPC parameters
+ * (order, shift, coefficients) differ from the exact-summation-order path, and the largest
+ * relative error of an autocorrelation lag.  The context's exact results are restored.
+ * Requires full blocks and 1 <= max_lpc_order <= 16. */
+int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *ctx, float *kernel_ms, uint32_t *compared,
+                                     uint32_t *params_differ, double *max_rel_err);
+
 /* Duration in milliseconds of each kernel of the last analyze call, measured with HIP events
  * on the launch stream (names via flacgpu_kernel_name).  Requires flacgpu_set_timing(ctx, 1). */
 #define FLACGPU_N_KERNELS 12

@@ -140,3 +140,18 @@ def test_roundtrip_fixture_files():  # tests/format.rs:207-435 inputs
     for ch in (1, 2, 4, 8):
         for bps in (8, 16, 24):
             run_case(read_raw(f"roundtrip-{ch}-{bps}-4777.raw", bps), ch, bps, max_po=5, max_lpc=8)
+
+
+def test_mfma_autocorr_experiment_is_close_but_not_the_product_path():
+    """The f64-MFMA autocorrelation experiment agrees with the exact path to rounding error,
+    and running it leaves the context's exact results untouched."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    pcm = synth_fast(95, 2, 24, 4096 * 16)
+    an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=16)
+    plans0, subs0, res0 = an.analyze(pcm, 16, 4096)
+    r = an.experiment_mfma_autocorr()
+    assert r["compared"] == 64 and r["max_rel_err"] < 1e-9
+    plans1, subs1, res1 = an.fetch(16)
+    assert bytes(subs0) == bytes(subs1) and np.array_equal(res0, res1)
+    an.close()
