@@ -102,6 +102,8 @@ void put_block_header(std::vector<uint8_t> &v, bool last, uint8_t type, uint32_t
 }
 
 struct MetaLayout {
+    bool vorbis = false;              // a VORBIS_COMMENT block is present (sorts first)
+    std::vector<uint8_t> vorbis_body;
     bool seektable = false;           // a SEEKTABLE block is present
     bool seektable_after_padding = false;  // inserted at finalize => pushed last
     std::vector<SeekPoint> points;
@@ -112,7 +114,7 @@ struct MetaLayout {
 std::vector<uint8_t> build_metadata(const StreamInfo &si, const MetaLayout &m) {
     std::vector<uint8_t> v;
     v.insert(v.end(), {'f', 'L', 'a', 'C'});
-    int remaining = (m.seektable ? 1 : 0) + (m.padding ? 1 : 0);
+    int remaining = (m.seektable ? 1 : 0) + (m.padding ? 1 : 0) + (m.vorbis ? 1 : 0);
     put_block_header(v, remaining == 0, 0, 34);
     put_be(v, si.min_block, 2);
     put_be(v, si.max_block, 2);
@@ -144,7 +146,12 @@ std::vector<uint8_t> build_metadata(const StreamInfo &si, const MetaLayout &m) {
         put_block_header(v, remaining == 0, 1, m.padding_size);
         v.insert(v.end(), m.padding_size, 0);
     };
-    // block order after Encoder::new's sort (encode.rs:1944-1951): SEEKTABLE < PADDING;
+    if (m.vorbis) {  // VorbisComment::to_writer, metadata/mod.rs:2512-2536
+        remaining--;
+        put_block_header(v, remaining == 0, 4, static_cast<uint32_t>(m.vorbis_body.size()));
+        v.insert(v.end(), m.vorbis_body.begin(), m.vorbis_body.end());
+    }
+    // block order after Encoder::new's sort (encode.rs:1944-1951): VORBIS_COMMENT < SEEKTABLE < PADDING;
     // a SEEKTABLE created at finalize is pushed behind PADDING (metadata/mod.rs:4425-4441)
     if (m.seektable && !m.seektable_after_padding) emit_seektable();
     if (m.padding) emit_padding();
@@ -289,6 +296,24 @@ struct flacenc_writer {
         bytes_per_sample = (bps + 7) / 8;
         meta.padding = o.padding > 0;
         meta.padding_size = static_cast<uint32_t>(o.padding);
+        if (o.n_comment_fields || o.vendor_string) {
+            auto put_le32 = [&](uint32_t x) {
+                for (int i = 0; i < 4; i++) meta.vorbis_body.push_back(static_cast<uint8_t>(x >> (8 * i)));
+            };
+            const std::string vendor = o.vendor_string ? o.vendor_string : "flac-codec 1.3.2";
+            put_le32(static_cast<uint32_t>(vendor.size()));
+            meta.vorbis_body.insert(meta.vorbis_body.end(), vendor.begin(), vendor.end());
+            put_le32(o.n_comment_fields);
+            for (uint32_t i = 0; i < o.n_comment_fields; i++) {
+                const std::string f = o.comment_fields[i];
+                put_le32(static_cast<uint32_t>(f.size()));
+                meta.vorbis_body.insert(meta.vorbis_body.end(), f.begin(), f.end());
+            }
+            meta.vorbis = true;
+        }
+        // the writer keeps no pointers into caller memory
+        o.vendor_string = nullptr;
+        o.comment_fields = nullptr;
         if (has_total && o.seektable_mode != FLACENC_SEEKTABLE_NONE) {
             // placeholder SEEKTABLE, encode.rs:1920-1939 + EncoderSeekPoint::placeholders :2131
             std::vector<SeekPoint> all;

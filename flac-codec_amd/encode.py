@@ -88,6 +88,10 @@ class _COptions(C.Structure):
         ("device", C.c_int32),
         ("pack_threads", C.c_uint32),
         ("host_pack", C.c_uint32),
+        ("vendor_string", C.c_char_p),
+        ("comment_fields", C.POINTER(C.c_char_p)),
+        ("n_comment_fields", C.c_uint32),
+        ("reserved2", C.c_uint32),
     ]
 
 
@@ -185,6 +189,8 @@ class Options:
         self._c = _COptions()
         getattr(_stream_lib(), "flacenc_options_" + preset)(C.byref(self._c))
         self._clobber = False
+        self._vendor = None      # VORBIS_COMMENT vendor string (None = reference default)
+        self._fields = None      # list of "NAME=value" strings, None = no block
 
     # presets, encode.rs:1376-1408, 1635-1657
     @classmethod
@@ -241,6 +247,31 @@ class Options:
     def no_padding(self):  # encode.rs:1505
         self._c.padding = 0
         return self
+
+    def tag(self, field, value):  # encode.rs:1513: adds NAME=value, creating the block if needed
+        if "=" in field:
+            raise ValueError("field must not contain '='")  # the reference panics (metadata/mod.rs:2357)
+        if self._fields is None:
+            self._fields = []
+        self._fields.append(f"{field}={value}")
+        return self
+
+    def comment(self, fields, vendor_string=None):  # encode.rs:1525: replaces the whole block
+        self._fields = list(fields)
+        self._vendor = vendor_string
+        return self
+
+    def _c_options(self):
+        """The C struct with the VORBIS_COMMENT pointers filled in (kept alive on self)."""
+        if self._fields is None:
+            self._c.vendor_string, self._c.n_comment_fields = None, 0
+            self._c.comment_fields = None
+        else:
+            self._keep = (C.c_char_p * max(len(self._fields), 1))(*[f.encode() for f in self._fields])
+            self._c.comment_fields = self._keep
+            self._c.n_comment_fields = len(self._fields)
+            self._c.vendor_string = (self._vendor or "flac-codec 1.3.2").encode()
+        return self._c
 
     def seektable_seconds(self, seconds):  # encode.rs:1568
         self._c.seektable_mode, self._c.seektable_value = (1, seconds & 0xFF) if seconds else (0, 0)
@@ -357,7 +388,7 @@ class FlacSampleWriter(_Writer):
         super().__init__(writer)
         ht, tv = _total(total_samples)
         _check(_stream_lib().flacenc_sample_writer_new(
-            C.byref(options._c), sample_rate, bits_per_sample, channels, ht, tv, self._sink_ptr(),
+            C.byref(options._c_options()), sample_rate, bits_per_sample, channels, ht, tv, self._sink_ptr(),
             C.byref(self._h)))
 
     @classmethod
@@ -383,7 +414,7 @@ class FlacByteWriter(_Writer, io.RawIOBase):
         _Writer.__init__(self, writer)
         ht, tv = _total(total_bytes)
         _check(_stream_lib().flacenc_byte_writer_new(
-            C.byref(options._c), sample_rate, bits_per_sample, channels, ht, tv,
+            C.byref(options._c_options()), sample_rate, bits_per_sample, channels, ht, tv,
             int(endian == "big"), self._sink_ptr(), C.byref(self._h)))
 
     @classmethod
@@ -420,7 +451,7 @@ class FlacChannelWriter(_Writer):
         self._channels = channels
         ht, tv = _total(total_samples)
         _check(_stream_lib().flacenc_channel_writer_new(
-            C.byref(options._c), sample_rate, bits_per_sample, channels, ht, tv, self._sink_ptr(),
+            C.byref(options._c_options()), sample_rate, bits_per_sample, channels, ht, tv, self._sink_ptr(),
             C.byref(self._h)))
 
     @classmethod
@@ -457,7 +488,7 @@ class FlacStreamWriter:
             self._cb = (_WRITE_FN(_w), _SEEK_FN(lambda _u, _o: 1))
             self._sink = _CSink(self._cb[0], self._cb[1], None, 0)
         _check(_stream_lib().flacenc_stream_writer_new(
-            C.byref(options._c), C.byref(self._sink) if self._sink is not None else None,
+            C.byref(options._c_options()), C.byref(self._sink) if self._sink is not None else None,
             C.byref(self._h)))
 
     def write(self, sample_rate, channels, bits_per_sample, samples):  # encode.rs:1142

@@ -82,6 +82,14 @@ typedef struct {
     uint32_t host_pack;           /* 0: frames are assembled on the GPU (k_layout/k_pack/k_crc);
                                      1: Rice bit-packing + CRC stay on the host, as in the
                                      north-star split (same bytes either way) */
+    /* VORBIS_COMMENT (Options::tag / Options::comment, encode.rs:1513-1528).  n_comment_fields
+     * == 0 and vendor_string == NULL: no block.  Fields are "NAME=value" strings; a NULL
+     * vendor_string with fields present means VorbisComment::default()'s "flac-codec 1.3.2"
+     * (metadata/mod.rs:2225-2232).  The pointers are only read during *_writer_new. */
+    const char *vendor_string;
+    const char *const *comment_fields;
+    uint32_t n_comment_fields;
+    uint32_t reserved2;
 } flacenc_options;
 
 void flacenc_options_default(flacenc_options *o); /* Options::default(), encode.rs:1376-1408 */

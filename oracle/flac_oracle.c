@@ -1359,6 +1359,8 @@ typedef struct {
     size_t n_placeholder;
     int has_padding;
     uint32_t padding;
+    uint8_t *vc_body;  /* serialized VORBIS_COMMENT body, NULL = no block */
+    size_t vc_len;
     bitw out;          /* whole file in memory */
     size_t frames_start;
     uint64_t frame_number, samples_written;
@@ -1376,9 +1378,14 @@ static void write_all_blocks(encoder *e, bitw *w, const seekpoint *pts, size_t n
      * finalize is pushed after PADDING (metadata/mod.rs:4425-4441) */
     bw_put(w, 32, 0x664C6143u);
     int has_st = (pts != NULL);
-    int n_after = (has_st ? 1 : 0) + (e->has_padding ? 1 : 0);
+    int n_after = (has_st ? 1 : 0) + (e->has_padding ? 1 : 0) + (e->vc_body ? 1 : 0);
     write_block_header(w, n_after == 0, 0, 34);
     write_streaminfo(w, &e->si);
+    if (e->vc_body) { /* VorbisComment sorts first (encode.rs:1945) */
+        n_after--;
+        write_block_header(w, n_after == 0, 4, (uint32_t)e->vc_len);
+        for (size_t i = 0; i < e->vc_len; i++) bw_put(w, 8, e->vc_body[i]);
+    }
     for (int pass = 0; pass < 2; pass++) {
         int do_st = has_st && ((pass == 0) != (seektable_after_padding != 0));
         int do_pad = e->has_padding && ((pass == 0) == (seektable_after_padding != 0));
@@ -1406,10 +1413,33 @@ static void write_all_blocks(encoder *e, bitw *w, const seekpoint *pts, size_t n
     }
 }
 
-static int encoder_new(encoder *e, const orc_options *o, uint32_t sample_rate, uint32_t bps,
+static void put_le32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+/* VorbisComment::to_writer, metadata/mod.rs:2512-2536 */
+static uint8_t *serialize_vc(const orc_vorbis_comment *vc, size_t *len) {
+    const char *vendor = vc->vendor ? vc->vendor : "flac-codec 1.3.2";
+    size_t n = 4 + strlen(vendor) + 4;
+    for (uint32_t i = 0; i < vc->n_fields; i++) n += 4 + strlen(vc->fields[i]);
+    uint8_t *b = (uint8_t *)malloc(n), *p = b;
+    put_le32(p, (uint32_t)strlen(vendor)); p += 4;
+    memcpy(p, vendor, strlen(vendor)); p += strlen(vendor);
+    put_le32(p, vc->n_fields); p += 4;
+    for (uint32_t i = 0; i < vc->n_fields; i++) {
+        size_t l = strlen(vc->fields[i]);
+        put_le32(p, (uint32_t)l); p += 4;
+        memcpy(p, vc->fields[i], l); p += l;
+    }
+    *len = n;
+    return b;
+}
+
+static int encoder_new(encoder *e, const orc_options *o, const orc_vorbis_comment *vc,
+                       uint32_t sample_rate, uint32_t bps,
                        uint32_t channels, uint64_t total_pcm_frames /* 0 = None */) {
     memset(e, 0, sizeof *e);
     e->o = *o;
+    if (vc) e->vc_body = serialize_vc(vc, &e->vc_len);
     if (validate_options(o)) return ORC_ERR_OPTIONS;
     if (sample_rate >= 1048576) return ORC_ERR_INVALID_SAMPLE_RATE; /* :1899 */
     if (channels < 1 || channels > 8) return ORC_ERR_EXCESSIVE_CHANNELS; /* :1904 */
@@ -1532,6 +1562,7 @@ static int encoder_finalize(encoder *e) {
 static void encoder_free(encoder *e) {
     caches_free(&e->caches);
     free(e->seekpoints);
+    free(e->vc_body);
 }
 
 /* update_md5, encode.rs:1292-1318 (+ byteorder.rs:60-72 for 24-bit) */
@@ -1592,6 +1623,14 @@ int orc_encode_stream(const orc_options *opts, uint32_t sample_rate, uint32_t bp
                       uint32_t channels, const int32_t *interleaved, uint64_t n_interleaved,
                       int total_known, int threads, uint8_t **out, size_t *out_len,
                       orc_stream_stats *stats) {
+    return orc_encode_stream_vc(opts, NULL, sample_rate, bps, channels, interleaved, n_interleaved,
+                                total_known, threads, out, out_len, stats);
+}
+
+int orc_encode_stream_vc(const orc_options *opts, const orc_vorbis_comment *vc,
+                         uint32_t sample_rate, uint32_t bps, uint32_t channels,
+                         const int32_t *interleaved, uint64_t n_interleaved, int total_known,
+                         int threads, uint8_t **out, size_t *out_len, orc_stream_stats *stats) {
     if (bps < 1 || bps > 32) return ORC_ERR_INVALID_BPS; /* :495 */
     if (channels < 1 || channels > 8) return ORC_ERR_EXCESSIVE_CHANNELS;
     uint64_t total = 0;
@@ -1601,7 +1640,7 @@ int orc_encode_stream(const orc_options *opts, uint32_t sample_rate, uint32_t bp
         if (total == 0) return ORC_ERR_INVALID_TOTAL;
     }
     encoder e;
-    int rc = encoder_new(&e, opts, sample_rate, bps, channels, total);
+    int rc = encoder_new(&e, opts, vc, sample_rate, bps, channels, total);
     if (rc) return rc;
     unsigned bytes = (bps + 7) / 8;
     uint32_t block = opts->block_size;

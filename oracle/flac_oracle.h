@@ -167,6 +167,21 @@ enum {
  * passes Some(n_interleaved) as total_samples (placeholder SEEKTABLE).
  * threads: 1 = sequential; >1 = frame-parallel workers (NOT something the
  * reference does; output is identical, used only as a stronger CPU point). */
+/* VORBIS_COMMENT block (metadata/mod.rs:2218-2232, 2512-2536).  vendor == NULL means
+ * VorbisComment::default()'s "flac-codec 1.3.2"; fields are "NAME=value" strings as built by
+ * Options::tag (encode.rs:1513-1520 -> VorbisComment::insert, metadata/mod.rs:2353-2360). */
+typedef struct {
+    const char *vendor;
+    const char *const *fields;
+    uint32_t n_fields;
+} orc_vorbis_comment;
+
+/* orc_encode_stream with an optional VORBIS_COMMENT (NULL = none) */
+int orc_encode_stream_vc(const orc_options *opts, const orc_vorbis_comment *vc,
+                         uint32_t sample_rate, uint32_t bps, uint32_t channels,
+                         const int32_t *interleaved, uint64_t n_interleaved, int total_known,
+                         int threads, uint8_t **out, size_t *out_len, orc_stream_stats *stats);
+
 int orc_encode_stream(const orc_options *opts, uint32_t sample_rate, uint32_t bps,
                       uint32_t channels, const int32_t *interleaved, uint64_t n_interleaved,
                       int total_known, int threads, uint8_t **out, size_t *out_len,

@@ -81,6 +81,10 @@ class StreamStats(C.Structure):
     ]
 
 
+class VorbisComment(C.Structure):
+    _fields_ = [("vendor", C.c_char_p), ("fields", C.POINTER(C.c_char_p)), ("n_fields", C.c_uint32)]
+
+
 class DecodedInfo(C.Structure):
     _fields_ = [
         ("sample_rate", C.c_uint32),
@@ -137,6 +141,10 @@ def lib():
         L.orc_encode_stream.argtypes = [
             C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_uint32, ip, C.c_uint64, C.c_int,
             C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(StreamStats)]
+        L.orc_encode_stream_vc.argtypes = [
+            C.POINTER(Options), C.POINTER(VorbisComment), C.c_uint32, C.c_uint32, C.c_uint32, ip,
+            C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+            C.POINTER(StreamStats)]
         L.orc_decode_stream.argtypes = [
             C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
             C.POINTER(DecodedInfo)]
@@ -245,15 +253,21 @@ def subframe_residuals(sub_plan, cand_samples):
     return out[:cnt].copy()
 
 
-def encode_stream(opts, sample_rate, bps, channels, interleaved, total_known=True, threads=1):
-    """Returns (rc, flac_bytes, StreamStats)."""
+def encode_stream(opts, sample_rate, bps, channels, interleaved, total_known=True, threads=1,
+                  tags=None, vendor=None):
+    """Returns (rc, flac_bytes, StreamStats).  tags: list of "NAME=value" strings."""
     s = np.ascontiguousarray(interleaved, dtype=np.int32)
     out = C.c_void_p(None)
     out_len = C.c_size_t(0)
     st = StreamStats()
-    rc = lib().orc_encode_stream(C.byref(opts), sample_rate, bps, channels, _iptr(s), s.size,
-                                 int(total_known), threads, C.byref(out), C.byref(out_len),
-                                 C.byref(st))
+    vc = None
+    if tags is not None:
+        arr = (C.c_char_p * max(len(tags), 1))(*[t.encode() for t in tags])
+        vc = VorbisComment(vendor.encode() if vendor else None, arr, len(tags))
+    rc = lib().orc_encode_stream_vc(C.byref(opts), C.byref(vc) if vc is not None else None,
+                                    sample_rate, bps, channels, _iptr(s), s.size,
+                                    int(total_known), threads, C.byref(out), C.byref(out_len),
+                                    C.byref(st))
     data = C.string_at(out, out_len.value) if out.value else b""
     if out.value:
         lib().orc_free(out)

@@ -201,3 +201,23 @@ def test_fractional(bs, total):  # tests/format.rs:136-205
     pcm = noise[: total * 2]
     data = encode_samples(opts, 44100, 16, 2, pcm)
     check_stream(data, pcm, 44100, 16, 2, opts, True)
+
+
+def test_vorbis_comment_tags():  # Options::tag, encode.rs:1513-1520; block order :1944-1951
+    from flac_codec_amd.encode import Options
+
+    pcm = synth_fast(120, 2, 16, 4096 * 3 + 7)
+    for total_known in (True, False):
+        opts = Options.default().tag("TITLE", "Test").tag("WAVEFORMATEXTENSIBLE_CHANNEL_MASK", "0x0003")
+        data = encode_samples(opts, 44100, 16, 2, pcm, total_known=total_known)
+        rc, ref, _ = orc.encode_stream(orc_opts_from(opts), 44100, 16, 2, pcm, total_known=total_known,
+                                       tags=["TITLE=Test", "WAVEFORMATEXTENSIBLE_CHANNEL_MASK=0x0003"])
+        assert rc == 0 and data == ref
+        assert data[42] & 0x7F == 4  # VORBIS_COMMENT directly after STREAMINFO
+        assert b"flac-codec 1.3.2" in data[:200]
+        rc2, out, info = orc.decode_stream(data)
+        assert rc2 == 0 and info.md5_ok == 1 and np.array_equal(out, pcm)
+    opts = Options.default().no_padding().no_seektable().comment(["A=b"], vendor_string="me")
+    data = encode_samples(opts, 44100, 16, 2, pcm)
+    rc, ref, _ = orc.encode_stream(orc_opts_from(opts), 44100, 16, 2, pcm, tags=["A=b"], vendor="me")
+    assert rc == 0 and data == ref and data[42] == 0x84  # last-block flag on the comment
