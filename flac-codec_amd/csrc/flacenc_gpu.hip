@@ -891,14 +891,15 @@ __device__ __forceinline__ void ac_block_w(double (&hist)[H], double (&acc)[LG],
     }
 }
 
-template <int H, int A, int LG, int KB, int LDT, int LDW>
+template <int H, int A, int LG, int KB, int LDT, int LDW, int NW>
 __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXROWS * LDT],
                                         double *wt, uint32_t frame0, uint32_t nframes, uint32_t n,
                                         const double *__restrict__ win) {
     constexpr int TS = H * KB;          // samples per tile
     constexpr int Q = TS / 4;           // int4 per row per tile
-    constexpr int NLOAD = (AC_MAXROWS * Q + WG - 1) / WG;
-    constexpr int CW = (TS + 3) / 4;    // columns converted per wave
+    constexpr int NT = 64 * NW;         // threads per workgroup
+    constexpr int NLOAD = (AC_MAXROWS * Q + NT - 1) / NT;
+    constexpr int CW = (TS + NW - 1) / NW;  // columns converted per wave
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t total = nframes * p.ncand;
     const uint32_t cand0 = blockIdx.x * 64;
@@ -932,7 +933,7 @@ __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXR
     auto fetch = [&](uint32_t t) {
 #pragma unroll
         for (int k = 0; k < NLOAD; k++) {
-            const uint32_t idx = tid + k * WG;
+            const uint32_t idx = tid + k * NT;
             const uint32_t r = idx / Q, c4 = idx - r * Q;
             const uint32_t col = t * TS + 4 * c4;
             stage[k] = (r < nrows && col < p.ldb)
@@ -943,7 +944,7 @@ __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXR
     auto commit = [&](uint32_t buf) {
 #pragma unroll
         for (int k = 0; k < NLOAD; k++) {
-            const uint32_t idx = tid + k * WG;
+            const uint32_t idx = tid + k * NT;
             const uint32_t r = idx / Q, c4 = idx - r * Q;
             if (r < AC_MAXROWS) *reinterpret_cast<int4 *>(&tile[buf][r * LDT + 4 * c4]) = stage[k];
         }
@@ -992,20 +993,31 @@ __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXR
     }
 }
 
-template <int H>
-__global__ void __launch_bounds__(WG) k_autocorr2(Params p, uint32_t frame0, uint32_t nframes,
-                                                  uint32_t n, const double *__restrict__ win) {
-    constexpr int LG = H / 4;
+template <int H, int NW>
+__global__ void __launch_bounds__(64 * NW) k_autocorr2(Params p, uint32_t frame0, uint32_t nframes,
+                                                       uint32_t n, const double *__restrict__ win) {
+    constexpr int LG = H / NW;       // lags per wave (lag group)
     constexpr int KB = (64 / H) > 0 ? (64 / H) : 1;
     constexpr int LDT = H * KB + 4;  // int row stride: 16-byte aligned rows
     constexpr int LDW = H * KB + 1;  // f64 row stride: odd => lanes (= rows) hit distinct banks
     __shared__ __attribute__((aligned(16))) int32_t tile[2][AC_MAXROWS * LDT];
     __shared__ double wt[64 * LDW];
-    switch (threadIdx.x >> 6) {  // wave = lag group; each wave runs its own statically indexed code
-    case 0: ac_wave<H, 0 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
-    case 1: ac_wave<H, 1 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
-    case 2: ac_wave<H, 2 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
-    default: ac_wave<H, 3 * LG, LG, KB, LDT, LDW>(p, tile, wt, frame0, nframes, n, win); break;
+    // wave = lag group; each wave runs its own statically indexed code
+    switch (threadIdx.x >> 6) {
+    case 0: ac_wave<H, 0 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+    case 1: ac_wave<H, 1 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+    case 2: ac_wave<H, 2 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+    case 3: ac_wave<H, 3 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+    default:
+        if constexpr (NW == 8) {
+            switch (threadIdx.x >> 6) {
+            case 4: ac_wave<H, 4 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+            case 5: ac_wave<H, 5 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+            case 6: ac_wave<H, 6 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+            default: ac_wave<H, 7 * LG, LG, KB, LDT, LDW, NW>(p, tile, wt, frame0, nframes, n, win); break;
+            }
+        }
+        break;
     }
 }
 
@@ -2332,7 +2344,14 @@ void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr<H>), grid, dim3(64), 0, st, p, frame0, nframes,
                            n, win);
     } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
+        if constexpr (H % 8 == 0) {
+            if (getenv("FLACGPU_AC_NW8")) {  // experiment: 8 lag-group waves (slower: 0.43 vs 0.35 ms)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 8>), dim3((lanes + 63) / 64), dim3(512), 0,
+                                   st, p, frame0, nframes, n, win);
+                return;
+            }
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 4>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
                            frame0, nframes, n, win);
     }
 }
