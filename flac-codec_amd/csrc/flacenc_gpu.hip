@@ -1877,6 +1877,12 @@ __global__ void __launch_bounds__(WG) k_zero(PackParams q, uint32_t n_frames) {
         o[i] = make_uint4(0, 0, 0, 0);
 }
 
+// words reserved for a subframe's bit string: a chosen subframe is never longer than its
+// VERBATIM form (<= 40 + 33 n bits) plus the 16-byte frame header; multiple of 4 words
+__host__ __device__ constexpr uint32_t pack_sb_words(uint32_t block_size) {
+    return ((block_size * 33u / 32u + 32u) + 3u) & ~3u;
+}
+
 // OR a field of nbits (<= 32) at bit position pos of an MSB-first bit string held in LDS words
 __device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, uint32_t nbits) {
     if (nbits == 0) return;
@@ -1891,8 +1897,12 @@ __device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, 
     }
 }
 
-template <bool FAST>
+// MODE 0: any block length, residual rows read from HBM (written by k_emit)
+// MODE 1: 4096-sample blocks, residual rows read from HBM into registers
+// MODE 2: 4096-sample blocks, residuals RECOMPUTED from the PCM in registers (k_emit not needed)
+template <int MODE, int PREV>
 __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
+    constexpr bool FAST = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ uint32_t wave_tot[4];
     __shared__ uint8_t hdr[16];
@@ -1921,7 +1931,14 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     // lengths, then codes; the second pass hits L1/L2)
     const int32_t *__restrict__ r = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
     int32_t v16[16];  // FAST (n == 4096): this lane's residuals [16 tid, 16 tid + 16) in registers
-    if constexpr (FAST) {
+    // MODE 2 keeps the wasted-bit-shifted samples of the source candidate in LDS (20-dword rows)
+    int32_t *xs = lds + pack_sb_words(FN);
+    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+    auto rd = [&](uint32_t i) -> int32_t {
+        if constexpr (MODE == 2) return xs[(i >> 4) * 20 + (i & 15)];
+        else return r[i];
+    };
+    if constexpr (MODE == 1) {
         const int4 *pr = reinterpret_cast<const int4 *>(r) + 4 * tid;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
@@ -1929,7 +1946,70 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
             v16[4 * qd] = t4.x; v16[4 * qd + 1] = t4.y; v16[4 * qd + 2] = t4.z; v16[4 * qd + 3] = t4.w;
         }
     }
+    if constexpr (MODE == 2) {
+        uint32_t cand = sp->source;
+        if (p.stereo4) cand = cand == FLACGPU_SRC_MID ? 2u : cand == FLACGPU_SRC_SIDE ? 3u : cand;
+        const CandSrc src = cand_src(p, frame, cand);
+        load_cand16(src, tid, v16);
+#pragma unroll
+        for (int e = 0; e < 16; e++) v16[e] >>= wasted;
+        int4 *row = reinterpret_cast<int4 *>(xs + tid * 20);
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) row[qd] = make_int4(v16[4 * qd], v16[4 * qd + 1], v16[4 * qd + 2], v16[4 * qd + 3]);
+        if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = (type == FLACGPU_SUB_LPC && tid < order) ? sp->coeffs[tid] : 0;
+    }
     __syncthreads();
+    if constexpr (MODE == 2) {
+        if (type == FLACGPU_SUB_LPC) {  // same FIR as k_fir16 (encode.rs:3181-3197)
+            constexpr int PW = 16 * PREV + 16;
+            int32_t pw[PW];
+#pragma unroll
+            for (int e = 0; e < 16; e++) pw[16 * PREV + e] = v16[e];
+#pragma unroll
+            for (int rr = 0; rr < PREV; rr++) {
+                const int srcrow = (int)tid - PREV + rr;
+                const int4 *prow = reinterpret_cast<const int4 *>(xs + (srcrow < 0 ? 0 : srcrow) * 20);
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const int4 t4 = srcrow < 0 ? make_int4(0, 0, 0, 0) : prow[qd];
+                    pw[16 * rr + 4 * qd] = t4.x; pw[16 * rr + 4 * qd + 1] = t4.y;
+                    pw[16 * rr + 4 * qd + 2] = t4.z; pw[16 * rr + 4 * qd + 3] = t4.w;
+                }
+            }
+            const uint32_t shift = sp->shift;
+            if constexpr (PREV == 1) {
+                switch ((order + 3) >> 2) {
+                case 1: fir16<4, PW>(pw, qlp, shift, 16, v16); break;
+                case 2: fir16<8, PW>(pw, qlp, shift, 16, v16); break;
+                case 3: fir16<12, PW>(pw, qlp, shift, 16, v16); break;
+                default: fir16<16, PW>(pw, qlp, shift, 16, v16); break;
+                }
+            } else {
+                switch ((order + 3) >> 2) {
+                case 1: fir16<4, PW>(pw, qlp, shift, 16, v16); break;
+                case 2: fir16<8, PW>(pw, qlp, shift, 16, v16); break;
+                case 3: fir16<12, PW>(pw, qlp, shift, 16, v16); break;
+                case 4: fir16<16, PW>(pw, qlp, shift, 16, v16); break;
+                case 5: fir16<20, PW>(pw, qlp, shift, 16, v16); break;
+                case 6: fir16<24, PW>(pw, qlp, shift, 16, v16); break;
+                case 7: fir16<28, PW>(pw, qlp, shift, 16, v16); break;
+                default: fir16<32, PW>(pw, qlp, shift, 16, v16); break;
+                }
+            }
+        } else if (type == FLACGPU_SUB_FIXED && order > 0) {  // iterated differences, encode.rs:3039-3060
+            int32_t qv[20];
+            const int4 h = tid ? *reinterpret_cast<const int4 *>(xs + (tid - 1) * 20 + 12) : make_int4(0, 0, 0, 0);
+            qv[0] = h.x; qv[1] = h.y; qv[2] = h.z; qv[3] = h.w;
+#pragma unroll
+            for (int e = 0; e < 16; e++) qv[4 + e] = v16[e];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int32_t x0 = qv[e + 4], x1 = qv[e + 3], x2 = qv[e + 2], x3 = qv[e + 1], x4 = qv[e];
+                v16[e] = order == 1 ? x0 - x1 : order == 2 ? x0 - 2 * x1 + x2
+                       : order == 3 ? x0 - 3 * x1 + 3 * x2 - x3 : x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
+            }
+        }
+    }
 
     const uint32_t base = prefix_bits;  // bit where the subframe starts inside sb
     if (tid == 0) {
@@ -1971,14 +2051,14 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
             lds_put(sb, base + 7, 1, 1);
             lds_put(sb, base + 8 + (wasted - 1), 1, 1);  // wasted-1 zeros then a one
         }
-        if (type == FLACGPU_SUB_CONSTANT) lds_put(sb, base + 8 + wasted, (uint32_t)r[0], bps);
+        if (type == FLACGPU_SUB_CONSTANT) lds_put(sb, base + 8 + wasted, (uint32_t)rd(0), bps);
     }
     const uint32_t body0 = base + 8 + wasted;
     if (type == FLACGPU_SUB_VERBATIM) {
-        for (uint32_t i = tid; i < n; i += WG) lds_put(sb, body0 + i * bps, (uint32_t)r[i], bps);
+        for (uint32_t i = tid; i < n; i += WG) lds_put(sb, body0 + i * bps, (uint32_t)rd(i), bps);
     } else if (type == FLACGPU_SUB_FIXED || type == FLACGPU_SUB_LPC) {
         // warm-up, precision, shift, coefficients (encode.rs:3083-3085, 3118-3133)
-        if (tid < order) lds_put(sb, body0 + tid * bps, (uint32_t)r[tid], bps);
+        if (tid < order) lds_put(sb, body0 + tid * bps, (uint32_t)rd(tid), bps);
         uint32_t pos = body0 + order * bps;
         if (type == FLACGPU_SUB_LPC) {
             const uint32_t prec = sp->precision;
@@ -2247,6 +2327,7 @@ struct flacgpu_ctx {
     uint64_t *d_frame_off = nullptr;
     uint64_t packed_cap = 0;        // bytes
     bool packed_valid = false;
+    bool resid_valid = false;       // d_resid holds the rows of the last analysed batch
     Params last_params;
     uint32_t window_last_len = 0;
     hipStream_t own_stream = nullptr;
@@ -2331,9 +2412,7 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
 
 // dynamic LDS of k_pack: the residual row + the subframe's bit string (a chosen subframe is
 // never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
-size_t pack_lds_bytes(uint32_t block_size) {
-    return ((size_t)block_size * 33 / 32 + 32) * 4;
-}
+size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_size) * 4; }
 
 template <int H>
 void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
@@ -2447,7 +2526,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_pack<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)k_pack<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(pack_lds_bytes((uint32_t)B))));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
@@ -2595,8 +2674,9 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     }
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
-    begin(7);
-    hipLaunchKernelGGL(k_emit, dim3(n_frames * c->channels), dim3(WG), (size_t)B * sizeof(int32_t), st, p);
+    // the residual rows (k_emit) are produced lazily: flacgpu_fetch(residuals) / host packing
+    // need them, the device-side packer recomputes residuals in registers instead
+    c->resid_valid = false;
     if (c->timing) (void)hipEventRecord(c->ev[evi], st);
     HIP_TRY(hipGetLastError());
     c->last_frames = n_frames;
@@ -2615,12 +2695,26 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     return FLACGPU_OK;
 }
 
+static int ensure_residual_rows(flacgpu_ctx *c) {
+    if (c->resid_valid) return FLACGPU_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    const Params &p = c->last_params;
+    hipLaunchKernelGGL(k_emit, dim3(p.n_frames * p.channels), dim3(WG),
+                       (size_t)p.block_size * sizeof(int32_t), c->own_stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    c->resid_valid = true;
+    return FLACGPU_OK;
+}
+
 int flacgpu_fetch(flacgpu_ctx *c, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subs,
                   int32_t *residuals) {
     if (!c || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
     const size_t F = c->last_frames;
     hipStream_t st = c->own_stream;
     HIP_TRY(hipDeviceSynchronize());
+    if (residuals)
+        if (int rc = ensure_residual_rows(c)) return rc;
     if (plans) HIP_TRY(hipMemcpyAsync(plans, c->d_fplan, sizeof(*plans) * F, hipMemcpyDeviceToHost, st));
     if (subs)
         HIP_TRY(hipMemcpyAsync(subs, c->d_out, sizeof(*subs) * F * c->channels, hipMemcpyDeviceToHost, st));
@@ -2669,8 +2763,10 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
     if (c->timing) (void)hipEventRecord(ev[1], st);
-    {   // frames of exactly 4096 samples take the register fast path
-        const bool fast16 = p.block_size == FN && !getenv("FLACGPU_NO_FAST");
+    {   // frames of exactly 4096 samples take the register fast path, which recomputes the
+        // residuals from the PCM (k_emit is only run for the frames that need its rows)
+        const bool fast16 = p.block_size == FN && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
+                            !getenv("FLACGPU_NO_FAST");
         const uint32_t n_fast = fast16 ? (p.last_len == p.block_size ? p.n_frames : p.n_frames - 1) : 0;
         Params pf = p, pg = p;
         pf.f0 = 0;
@@ -2678,8 +2774,20 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
         pg.f0 = n_fast;
         pg.fcount = p.n_frames - n_fast;
         const size_t lds = pack_lds_bytes(p.block_size);
-        if (pf.fcount) hipLaunchKernelGGL(k_pack<true>, dim3(pf.fcount * p.channels), dim3(WG), lds, st, pf, q);
-        if (pg.fcount) hipLaunchKernelGGL(k_pack<false>, dim3(pg.fcount * p.channels), dim3(WG), lds, st, pg, q);
+        if (pf.fcount) {
+            const size_t lds2 = lds + WG * 20 * sizeof(int32_t);
+            if (p.max_lpc_order <= 16)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<2, 1>), dim3(pf.fcount * p.channels), dim3(WG), lds2, st, pf, q);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<2, 2>), dim3(pf.fcount * p.channels), dim3(WG), lds2, st, pf, q);
+        }
+        if (pg.fcount) {
+            if (!c->resid_valid) {  // residual rows of these frames
+                hipLaunchKernelGGL(k_emit, dim3(pg.fcount * p.channels), dim3(WG),
+                                   (size_t)p.block_size * sizeof(int32_t), st, pg);
+            }
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<0, 1>), dim3(pg.fcount * p.channels), dim3(WG), lds, st, pg, q);
+        }
     }
     if (c->timing) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_crc, dim3(p.n_frames), dim3(WG), 0, st, p, q);
@@ -2810,7 +2918,7 @@ void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     switch (which) {
     case 0: return c->d_fplan;
     case 1: return c->d_out;
-    case 2: return c->d_resid;
+    case 2: return ensure_residual_rows(c) == FLACGPU_OK ? c->d_resid : nullptr;
     case 3: return c->d_planar;
     case 4: return c->d_packed;
     case 5: return c->d_frame_off;
