@@ -524,20 +524,93 @@ __global__ void __launch_bounds__(WG) k_deinterleave(const int32_t *__restrict__
     }
 }
 
-// stereo fast path: both channels of an interleaved pair in one 8-byte load
+// stereo fast path: both channels of an interleaved pair in one 8-byte load.  Also ORs together
+// all samples of L, R, mid, side per frame (orbits[frame*ncand + c]): trailing zeros of the OR =
+// wasted bits (encode.rs:2878-2898), OR == 0 = all-zero candidate.
 __global__ void __launch_bounds__(WG) k_deinterleave2(const int2 *__restrict__ in,
                                                       int32_t *__restrict__ out,
                                                       uint32_t block_size, uint32_t ldb,
-                                                      uint32_t n_frames, uint32_t last_len) {
+                                                      uint32_t n_frames, uint32_t last_len,
+                                                      uint32_t *__restrict__ orbits, uint32_t ncand) {
     const uint32_t frame = blockIdx.y;
     const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
     const int2 *src = in + (size_t)frame * block_size;
     int32_t *o = out + (size_t)frame * 2 * ldb;
+    uint32_t ol = 0, orr = 0, om = 0, os = 0;
     for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
         int2 v = src[i];
         o[i] = v.x;
         o[ldb + i] = v.y;
+        ol |= (uint32_t)v.x;
+        orr |= (uint32_t)v.y;
+        om |= (uint32_t)combine(1, v.x, v.y);
+        os |= (uint32_t)combine(2, v.x, v.y);
     }
+    ol = wave_or_u32(ol);
+    orr = wave_or_u32(orr);
+    om = wave_or_u32(om);
+    os = wave_or_u32(os);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t *ob = orbits + (size_t)frame * ncand;
+        if (ol) atomicOr(&ob[0], ol);
+        if (orr) atomicOr(&ob[1], orr);
+        if (ncand == 4) {
+            if (om) atomicOr(&ob[2], om);
+            if (os) atomicOr(&ob[3], os);
+        }
+    }
+}
+
+// the same ORs from the planar buffer (every layout but interleaved stereo)
+__global__ void __launch_bounds__(WG) k_orbits(Params p, uint32_t *__restrict__ orbits) {
+    const uint32_t frame = blockIdx.y;
+    const uint32_t n = frame_len(p, frame);
+    const int32_t *base = p.planar + (size_t)frame * p.channels * p.ldb;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        if (p.stereo4) {
+            const int32_t l = base[i], r = base[p.ldb + i];
+            acc[0] |= (uint32_t)l;
+            acc[1] |= (uint32_t)r;
+            acc[2] |= (uint32_t)combine(1, l, r);
+            acc[3] |= (uint32_t)combine(2, l, r);
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++)
+                if (c < p.channels) acc[c] |= (uint32_t)base[(size_t)c * p.ldb + i];
+        }
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t v = wave_or_u32(acc[c]);
+        if ((threadIdx.x & 63) == 0 && c < p.ncand && v) atomicOr(&orbits[(size_t)frame * p.ncand + c], v);
+    }
+}
+
+// per (frame, candidate): activity, wasted bits, effective bps (encode.rs:2870-2898)
+__global__ void __launch_bounds__(WG) k_candinfo(Params p, const uint32_t *__restrict__ orbits) {
+    const uint32_t idx = blockIdx.x * WG + threadIdx.x;
+    if (idx >= p.n_frames * p.ncand) return;
+    const uint32_t cand = idx % p.ncand;
+    CandInfo ci;
+    if (p.exhaustive || !p.stereo4)
+        // exhaustive: L, R always; S if bps+1 <= 32 (guaranteed by stereo4); M iff mid_side
+        ci.active = !(p.stereo4 && cand == 2 && !p.mid_side);
+    else
+        ci.active = p.cinfo[idx].active;  // chosen by k_stereo_stats
+    const uint32_t cbps = p.bps + ((p.stereo4 && cand == 3) ? 1u : 0u);
+    const uint32_t orv = orbits[idx];
+    if (orv == 0) {  // all zero -> CONSTANT(0) at the candidate's bps, wasted 0
+        ci.is_const = 1;
+        ci.wasted = 0;
+        ci.bps = (uint8_t)cbps;
+    } else {
+        const uint32_t w = (uint32_t)__builtin_ctz(orv);
+        ci.is_const = 0;
+        ci.wasted = (uint8_t)w;
+        ci.bps = (uint8_t)(cbps - w);
+    }
+    p.cinfo[idx] = ci;
 }
 
 // ---------------------------------------------------------------------------------
@@ -606,41 +679,23 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
     const uint32_t n = frame_len(p, frame);
     const size_t cidx = (size_t)frame * p.ncand + cand;
     const uint32_t tid = threadIdx.x;
-    CandInfo *ci = p.cinfo + cidx;
-    if (p.exhaustive || !p.stereo4) {
-        // exhaustive: L, R always; S if bps+1 <= 32 (guaranteed by stereo4); M iff mid_side
-        if (p.stereo4 && cand == 2 && !p.mid_side) {
-            if (tid == 0) ci->active = 0;
-            return;
-        }
-        if (tid == 0) ci->active = 1;
-    } else if (!ci->active) {
-        return;  // k_stereo_stats deselected this candidate
-    }
+    const CandInfo ci = p.cinfo[cidx];  // written by k_candinfo (wasted bits, activity)
+    if (!ci.active) return;
     int32_t *x = lds;
     int32_t *r = lds + p.block_size;
     const CandSrc src = cand_src(p, frame, cand);
 
-    uint32_t orv = 0;
-    for (uint32_t i = tid; i < n; i += WG) {
-        int32_t v = combine(src.mode, src.a[i], src.b[i]);
-        x[i] = v;
-        orv |= (uint32_t)v;
-    }
-    orv = block_or_u32(orv, red);
+    for (uint32_t i = tid; i < n; i += WG) x[i] = combine(src.mode, src.a[i], src.b[i]);
     plan_clear(plan);
     __syncthreads();
-    // encode.rs:2878-2898: min trailing zeros over all samples (zero counts as 32)
-    const uint32_t wasted = orv ? (uint32_t)__builtin_ctz(orv) : 32u;
+    // encode.rs:2878-2898: min trailing zeros over all samples (zero counts as 32), from k_candinfo
+    const uint32_t wasted = ci.is_const ? 32u : ci.wasted;
     if (wasted == 32u) {  // all zero -> CONSTANT(0) at the candidate's bps, wasted 0 (:2883-2887)
         if (tid == 0) {
             plan.type = FLACGPU_SUB_CONSTANT;
             plan.bps = (uint8_t)src.bps;
             plan.source = src.source;
             plan.bits = 8u + src.bps;
-            ci->wasted = 0;
-            ci->bps = (uint8_t)src.bps;
-            ci->is_const = 1;
         }
         __syncthreads();
         plan_store(p.fixed_plan + cidx, plan);
@@ -739,9 +794,6 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
         plan.order = (uint8_t)order;
         plan.source = src.source;
         plan.bits = 8u + wasted + order * bps_eff + rbits;
-        ci->wasted = (uint8_t)wasted;
-        ci->bps = (uint8_t)bps_eff;
-        ci->is_const = 0;
     }
     __syncthreads();
     plan_store(p.fixed_plan + cidx, plan);
@@ -1390,26 +1442,14 @@ __global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
     const uint32_t n = FN;
     const size_t cidx = (size_t)frame * p.ncand + cand;
     const uint32_t tid = threadIdx.x;
-    CandInfo *ci = p.cinfo + cidx;
-    if (p.exhaustive || !p.stereo4) {
-        if (p.stereo4 && cand == 2 && !p.mid_side) {
-            if (tid == 0) ci->active = 0;
-            return;
-        }
-        if (tid == 0) ci->active = 1;
-    } else if (!ci->active) {
-        return;
-    }
+    const CandInfo ci = p.cinfo[cidx];  // written by k_candinfo (wasted bits, activity)
+    if (!ci.active) return;
     const CandSrc src = cand_src(p, frame, cand);
     int32_t x[16];
     load_cand16(src, tid, x);
-    uint32_t orv = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) orv |= (uint32_t)x[e];
     rice_init(RS);
-    orv = block_or_u32(orv, red);
     plan_clear(plan);
-    const uint32_t wasted = orv ? (uint32_t)__builtin_ctz(orv) : 32u;  // encode.rs:2878-2898
+    const uint32_t wasted = ci.is_const ? 32u : ci.wasted;  // encode.rs:2878-2898
     if (wasted == 32u) {
         __syncthreads();
         if (tid == 0) {
@@ -1417,9 +1457,6 @@ __global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
             plan.bps = (uint8_t)src.bps;
             plan.source = src.source;
             plan.bits = 8u + src.bps;
-            ci->wasted = 0;
-            ci->bps = (uint8_t)src.bps;
-            ci->is_const = 1;
         }
         __syncthreads();
         plan_store(p.fixed_plan + cidx, plan);
@@ -1488,9 +1525,6 @@ __global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
         plan.order = (uint8_t)order;
         plan.source = src.source;
         plan.bits = 8u + wasted + order * bps_eff + rbits;
-        ci->wasted = (uint8_t)wasted;
-        ci->bps = (uint8_t)bps_eff;
-        ci->is_const = 0;
     }
     __syncthreads();
     plan_store(p.fixed_plan + cidx, plan);
@@ -2323,6 +2357,9 @@ struct flacgpu_ctx {
     FrameInfo *d_finfo = nullptr;
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
+    uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
     uint64_t packed_cap = 0;        // bytes
@@ -2508,12 +2545,16 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     ALLOC(c->d_finfo, F);
     ALLOC(c->d_fplan, F);
     ALLOC(c->d_stats, 4);
+    ALLOC(c->d_orbits, F * NC);
     // worst case: every subframe VERBATIM at 32 bits + headers
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
     ALLOC(c->d_frame_off, F + 1);
 #undef ALLOC
     HIP_TRY(hipStreamCreate(&c->own_stream));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipMemsetAsync(c->d_planar, 0, sizeof(int32_t) * (F * C * c->ldb + slack), c->own_stream));
     HIP_TRY(hipMemsetAsync(c->d_cinfo, 0, sizeof(CandInfo) * F * NC, c->own_stream));
     double thr[128];
@@ -2540,7 +2581,10 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off);
+    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_orbits);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_ok) for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -2623,29 +2667,36 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     };
 
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(uint32_t), st));
-    // K0
+    const uint32_t ncb = n_frames * c->ncand;
+    HIP_TRY(hipMemsetAsync(c->d_orbits, 0, sizeof(uint32_t) * ncb, st));
+    // K0 (+ OR of every candidate's samples -> wasted bits)
     const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
     begin(0);
+    bool have_orbits = false;
     if (planar_direct) {
         p.planar = d_pcm;  // [frame][ch][B] with ldb == B
     } else {
-        dim3 grid((B + WG - 1) / WG, n_frames);
-        if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2)
+        dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames);  // 8 samples per lane
+        if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
             hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm,
-                               c->d_planar, B, c->ldb, n_frames, last_len);
-        else
+                               c->d_planar, B, c->ldb, n_frames, last_len, c->d_orbits, c->ncand);
+            have_orbits = true;
+        } else {
             hipLaunchKernelGGL(k_deinterleave, grid, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels,
                                B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR);
+        }
     }
-    const uint32_t ncb = n_frames * c->ncand;
+    if (!have_orbits)
+        hipLaunchKernelGGL(k_orbits, dim3(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames), dim3(WG), 0, st, p,
+                           c->d_orbits);
     const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
     if (c->stereo4 && !p.exhaustive) {
         begin(1);
         hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
     }
-    begin(2);
+    hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
-    // block sizes, a short last frame, candidates wider than 27 bits) the generic LDS ones
+    // block sizes, a short last frame, candidates wider than 25 bits) the generic LDS ones
     const bool fast16 = (B == FN) && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
     const uint32_t n_fast = fast16 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
     Params pf = p, pg = p;
@@ -2653,9 +2704,22 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = n_frames - n_fast;
-    if (pf.fcount) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
-    if (pg.fcount) hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
-    if (p.max_lpc_order > 0) {
+    // The FIXED analysis and the autocorrelation -> Levinson chain only share their input, so
+    // they run concurrently on two HIP streams (fork after k_candinfo, join before k_fir); the
+    // FIXED kernels are integer-VALU bound, the autocorrelation f64-VALU/LDS bound.  With
+    // per-kernel timing enabled everything is serialised on one stream.
+    const bool lpc = p.max_lpc_order > 0;
+    const bool fork = lpc && !c->timing && !getenv("FLACGPU_NO_FORK");
+    hipStream_t sf = fork ? c->aux_stream : st;
+    if (fork) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sf, c->ev_fork, 0));
+    }
+    begin(2);
+    if (pf.fcount) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, sf, pf);
+    if (pg.fcount) hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, sf, pg);
+    if (fork) HIP_TRY(hipEventRecord(c->ev_join, sf));
+    if (lpc) {
         const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
         begin(3);
         const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
@@ -2663,6 +2727,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
         begin(4);
         hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
+        if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         begin(5);
         if (pf.fcount) {
             if (p.max_lpc_order <= 16)
