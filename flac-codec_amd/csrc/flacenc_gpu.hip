@@ -1871,35 +1871,33 @@ __device__ __forceinline__ uint32_t header_bytes(const HeaderCodes &h) {
 
 __global__ void __launch_bounds__(1024) k_layout(Params p, PackParams q) {
     __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t carry;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < p.n_frames; base += 1024) {
-        const uint32_t f = base + tid;
-        uint64_t size = 0;
-        if (f < p.n_frames) {
-            const flacgpu_frame_plan fp = p.frame_plan[f];
-            HeaderCodes h = header_codes(fp.block_size, q.sample_rate, q.first_frame_number + f);
-            size = header_bytes(h) + ((uint64_t)fp.body_bits + 7) / 8 + 2;
-        }
-        // inclusive scan inside the wave, then across the 16 waves
-        uint64_t v = size;
+    // lane t owns the contiguous frames [t*chunk, (t+1)*chunk): serial sum, one block scan
+    const uint32_t chunk = (p.n_frames + 1023) / 1024;
+    const uint32_t lo = tid * chunk;
+    const uint32_t hi = lo + chunk < p.n_frames ? lo + chunk : p.n_frames;
+    auto frame_bytes = [&](uint32_t f) -> uint64_t {
+        const flacgpu_frame_plan fp = p.frame_plan[f];
+        HeaderCodes h = header_codes(fp.block_size, q.sample_rate, q.first_frame_number + f);
+        return header_bytes(h) + ((uint64_t)fp.body_bits + 7) / 8 + 2;
+    };
+    uint64_t mine = 0;
+    for (uint32_t f = lo; f < hi; f++) mine += frame_bytes(f);
+    uint64_t v = mine;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint64_t t = __shfl_up(v, off, 64);
-            if ((tid & 63) >= (uint32_t)off) v += t;
-        }
-        if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
-        __syncthreads();
-        uint64_t prefix = carry;
-        for (uint32_t w = 0; w < (tid >> 6); w++) prefix += wave_tot[w];
-        if (f < p.n_frames) q.frame_off[f] = prefix + v - size;
-        __syncthreads();
-        if (tid == 1023) carry = prefix + v;
-        __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+        uint64_t t = __shfl_up(v, off, 64);
+        if ((tid & 63) >= (uint32_t)off) v += t;
     }
-    if (tid == 0) q.frame_off[p.n_frames] = carry;
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
+    __syncthreads();
+    uint64_t prefix = v - mine;
+    for (uint32_t w = 0; w < (tid >> 6); w++) prefix += wave_tot[w];
+    for (uint32_t f = lo; f < hi; f++) {
+        q.frame_off[f] = prefix;
+        prefix += frame_bytes(f);
+    }
+    if (tid == 1023) q.frame_off[p.n_frames] = prefix;
 }
 
 // zero the part of the output buffer the frames will occupy (16 bytes per lane)
