@@ -1045,11 +1045,15 @@ __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXR
     }
 }
 
+#ifndef AC_TILE
+#define AC_TILE 64   // samples per LDS tile (32 + a 128-VGPR cap overlapped better with k_fixed16
+                     // but ran 0.55 instead of 0.35 ms on its own: net loss)
+#endif
 template <int H, int NW>
-__global__ void __launch_bounds__(64 * NW) k_autocorr2(Params p, uint32_t frame0, uint32_t nframes,
-                                                       uint32_t n, const double *__restrict__ win) {
+__global__ void __launch_bounds__(64 * NW)
+k_autocorr2(Params p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *__restrict__ win) {
     constexpr int LG = H / NW;       // lags per wave (lag group)
-    constexpr int KB = (64 / H) > 0 ? (64 / H) : 1;
+    constexpr int KB = (AC_TILE / H) > 0 ? (AC_TILE / H) : 1;
     constexpr int LDT = H * KB + 4;  // int row stride: 16-byte aligned rows
     constexpr int LDW = H * KB + 1;  // f64 row stride: odd => lanes (= rows) hit distinct banks
     __shared__ __attribute__((aligned(16))) int32_t tile[2][AC_MAXROWS * LDT];
