@@ -138,6 +138,13 @@ def main():
             for k, v in {**ms_a, **ms_b}.items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         an.set_timing(False)
+        # device-side decode + CRC verification of the frames just packed (round trip in HBM)
+        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+        an.pack_device(first_frame, RATE)
+        vres, vms = an.verify_device(RATE, first_frame)
+        assert (vres.bad_structure, vres.bad_crc16, vres.frames_pcm_differs) == (0, 0, 0)
+        verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
+                  "Msamples/s": round(F * BLOCK * CHANNELS / (vms * 1e-3) / 1e6, 1)}
         # experiment: the same autocorrelation on the f64 matrix cores (NOT bit-exact, not used)
         an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
         mf = an.experiment_mfma_autocorr()
@@ -238,6 +245,7 @@ def main():
             "cpu_baseline": cpu,
             "kernels": kernels,
             "mfma_autocorr_experiment": mfma_exp,
+            "device_verify": verify,
             "compression_ratio": round(compressed_bytes / (F * BLOCK * CHANNELS * 3), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
             "parity_checked_frames": check,

@@ -61,6 +61,18 @@ class FramePlan(C.Structure):
     ]
 
 
+class VerifyResult(C.Structure):
+    """flacgpu_verify_result."""
+    _fields_ = [
+        ("frames", C.c_uint32),
+        ("bad_structure", C.c_uint32),
+        ("bad_crc16", C.c_uint32),
+        ("frames_pcm_differs", C.c_uint32),
+        ("samples_differ", C.c_uint32),
+        ("compared_pcm", C.c_uint32),
+    ]
+
+
 class GpuStats(C.Structure):
     _fields_ = [
         ("frames", C.c_uint32),
@@ -112,6 +124,9 @@ def lib():
     L.flacenc_pack_frames.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, ip, C.c_uint32,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.flacgpu_verify_device.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(VerifyResult),
+                                        C.POINTER(C.c_float)]
+    L.flacgpu_fetch_decoded.argtypes = [vp, ip]
     L.flacgpu_experiment_mfma_autocorr.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32),
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]

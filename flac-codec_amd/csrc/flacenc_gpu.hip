@@ -2271,7 +2271,10 @@ struct CrcWeights {
 };
 __constant__ CrcWeights kCrcW = CrcWeights();
 
-__global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
+// VERIFY = false: store the CRC-16 behind the frame; true: compare with the stored one and
+// count mismatching frames in verify_counts[1]
+template <bool VERIFY>
+__global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q, uint32_t *verify_counts) {
     __shared__ uint16_t T[4][256];                 // slicing-by-4 tables
     __shared__ uint32_t buf[CRC_CHUNK / 4 + WG];   // one pad dword per 64-byte slice
     __shared__ uint32_t part[4];
@@ -2331,8 +2334,227 @@ __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q) {
     }
     if (tid == 0) {
         uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
-        ob[begin + len] = (uint8_t)(running >> 8);
-        ob[begin + len + 1] = (uint8_t)running;
+        if constexpr (VERIFY) {
+            const uint32_t stored = ((uint32_t)ob[begin + len] << 8) | ob[begin + len + 1];
+            if (stored != running) atomicAdd(&verify_counts[1], 1u);
+        } else {
+            ob[begin + len] = (uint8_t)(running >> 8);
+            ob[begin + len + 1] = (uint8_t)running;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Frame decoder + verifier: the reference's read_frame / read_subframes /
+// read_subframe / read_residuals / predict (decode.rs:1388-1436, 1494-1856) for frames whose
+// byte offsets are known (everything this encoder produces).  Rice decoding and LPC synthesis
+// are sequential inside a subframe, so ONE LANE decodes ONE FRAME: the parallelism is across
+// the thousands of frames of a batch.  Output: planar PCM [frame][channel][ldb].
+// verify_counts[0] frames with a header / structure error, [2] frames whose PCM differs from the
+// reference buffer (when given), [3] differing samples.
+// ---------------------------------------------------------------------------------
+struct BitReader {
+    const uint8_t *base;
+    uint64_t pos;  // absolute bit position
+    __device__ __forceinline__ uint32_t peek32() const {  // next 32 bits, MSB first
+        const uint8_t *b = base + (pos >> 3);
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) v = (v << 8) | b[i];
+        return (uint32_t)(v >> (8 - (pos & 7)));
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t n) {  // n in 0..32
+        if (n == 0) return 0;
+        const uint32_t v = peek32() >> (32 - n);
+        pos += n;
+        return v;
+    }
+    __device__ __forceinline__ int32_t get_signed(uint32_t n) {
+        const uint32_t v = get(n);
+        return n < 32 ? (int32_t)(v << (32 - n)) >> (32 - n) : (int32_t)v;
+    }
+    __device__ __forceinline__ uint32_t unary1() {  // zeros before the next 1 bit
+        uint32_t q = 0;
+        for (;;) {
+            const uint32_t w = peek32();
+            if (w) {
+                const uint32_t z = (uint32_t)__builtin_clz(w);
+                pos += z + 1;
+                return q + z;
+            }
+            q += 32;
+            pos += 32;
+            if (q > (1u << 24)) return q;  // corrupt stream guard
+        }
+    }
+};
+
+__global__ void __launch_bounds__(64) k_decode(Params p, PackParams q, int32_t *__restrict__ out,
+                                               const int32_t *__restrict__ expect,
+                                               uint32_t *verify_counts) {
+    const uint32_t frame = blockIdx.x * 64 + threadIdx.x;
+    if (frame >= p.n_frames) return;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(q.out_words);
+    BitReader r{bytes, q.frame_off[frame] * 8};
+    const uint64_t end_bit = q.frame_off[frame + 1] * 8;
+    bool bad = false;
+    // FrameHeader::parse, stream.rs:214-240
+    if (r.get(15) != 0x7FFC) bad = true;
+    r.get(1);
+    const uint32_t bcode = r.get(4), rcode = r.get(4), acode = r.get(4), pcode = r.get(3);
+    r.get(1);
+    {   // frame number (UTF-8 like), stream.rs:1244-1262
+        uint32_t ones = 0;
+        while (ones < 8 && r.get(1)) ones++;
+        if (ones == 0) r.get(7);
+        else if (ones == 1 || ones > 7) bad = true;
+        else {
+            r.get(7 - ones);
+            for (uint32_t i = 1; i < ones; i++) {
+                if (r.get(2) != 2) bad = true;
+                r.get(6);
+            }
+        }
+    }
+    uint32_t n;
+    switch (bcode) {
+    case 1: n = 192; break;
+    case 2: n = 576; break;
+    case 3: n = 1152; break;
+    case 4: n = 2304; break;
+    case 5: n = 4608; break;
+    case 6: n = r.get(8) + 1; break;
+    case 7: n = r.get(16) + 1; break;
+    case 0: n = 0; bad = true; break;
+    default: n = 256u << (bcode - 8); break;
+    }
+    if (rcode == 12) r.get(8);
+    else if (rcode == 13 || rcode == 14) r.get(16);
+    else if (rcode == 15) bad = true;
+    {   // CRC-8 over the header
+        const uint64_t hb0 = q.frame_off[frame], hb1 = r.pos >> 3;
+        uint32_t crc = 0;
+        for (uint64_t i = hb0; i < hb1; i++) {
+            crc ^= bytes[i];
+            for (int b = 0; b < 8; b++) crc = (crc & 0x80) ? ((crc << 1) ^ 0x07) & 0xFF : (crc << 1) & 0xFF;
+        }
+        if (r.get(8) != crc) bad = true;
+    }
+    const uint32_t bps_tab[8] = {0, 8, 12, 0, 16, 20, 24, 32};
+    const uint32_t bps = pcode ? bps_tab[pcode] : p.bps;
+    const uint32_t nch = acode < 8 ? acode + 1 : 2;
+    if (n != frame_len(p, frame) || bps != p.bps || nch != p.channels || acode > 10) bad = true;
+    int32_t *rows = out + (size_t)frame * p.channels * p.ldb;
+    for (uint32_t c = 0; c < nch && !bad; c++) {
+        int32_t *x = rows + (size_t)c * p.ldb;
+        uint32_t sbps = bps;
+        if ((acode == 8 && c == 1) || (acode == 9 && c == 0) || (acode == 10 && c == 1)) sbps++;
+        // SubframeHeader, stream.rs:1375-1388
+        if (r.get(1)) bad = true;
+        const uint32_t type = r.get(6);
+        uint32_t wasted = 0;
+        if (r.get(1)) wasted = r.unary1() + 1;
+        if (wasted >= sbps) { bad = true; break; }
+        const uint32_t eb = sbps - wasted;
+        uint32_t order = 0;
+        int32_t coef[32];
+        uint32_t shift = 0;
+        bool has_res = false;
+        if (type == 0) {  // CONSTANT
+            const int32_t v = r.get_signed(eb);
+            for (uint32_t i = 0; i < n; i++) x[i] = v;
+        } else if (type == 1) {  // VERBATIM
+            for (uint32_t i = 0; i < n; i++) x[i] = r.get_signed(eb);
+        } else if (type >= 8 && type <= 12) {  // FIXED, decode.rs:1683-1702
+            order = type - 8;
+            const int32_t fc[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+            for (uint32_t j = 0; j < 4; j++) coef[j] = fc[order][j];
+            has_res = true;
+        } else if (type >= 32) {  // LPC, decode.rs:1704-1736
+            order = type - 31;
+            has_res = true;
+        } else {
+            bad = true;
+            break;
+        }
+        if (has_res) {
+            if (order > n) { bad = true; break; }
+            for (uint32_t i = 0; i < order; i++) x[i] = r.get_signed(eb);
+            if (type >= 32) {
+                const uint32_t prec = r.get(4) + 1;
+                if (prec == 16) bad = true;
+                const int32_t sh = r.get_signed(5);
+                if (sh < 0) bad = true;
+                shift = (uint32_t)sh;
+                for (uint32_t j = 0; j < order; j++) coef[j] = r.get_signed(prec);
+            }
+            // read_residuals (decode.rs:1800-1856) fused with predict (decode.rs:1738-1752)
+            const uint32_t method = r.get(2);
+            if (method > 1) { bad = true; break; }
+            const uint32_t hb = method ? 5u : 4u, esc = method ? 31u : 15u;
+            const uint32_t po = r.get(4);
+            const uint32_t plen = n >> po;
+            uint32_t i = order;
+            for (uint32_t part = 0; part < (1u << po) && !bad; part++) {
+                uint32_t cnt = plen;
+                if (part == 0) {
+                    if (plen < order) { bad = true; break; }
+                    cnt = plen - order;
+                }
+                const uint32_t k = r.get(hb);
+                const uint32_t ebits = k == esc ? r.get(5) : 0;
+                for (uint32_t t = 0; t < cnt; t++, i++) {
+                    int32_t res;
+                    if (k == esc) {
+                        res = ebits ? r.get_signed(ebits) : 0;
+                    } else {
+                        const uint32_t qn = r.unary1();
+                        const uint32_t u = (qn << k) | r.get(k);
+                        res = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+                    }
+                    long long s = 0;
+                    for (uint32_t j = 0; j < order; j++) s += (long long)x[i - 1 - j] * (long long)coef[j];
+                    x[i] = res + (int32_t)(s >> shift);
+                }
+                if (r.pos > end_bit) bad = true;
+            }
+            if (i != n) bad = true;
+        }
+        if (wasted)
+            for (uint32_t i = 0; i < n; i++) x[i] = (int32_t)((uint32_t)x[i] << wasted);
+    }
+    if (!bad && acode >= 8) {  // undo the stereo decorrelation, decode.rs:1520-1628
+        int32_t *c0 = rows, *c1 = rows + p.ldb;
+        for (uint32_t i = 0; i < n; i++) {
+            const long long a = c0[i], b = c1[i];
+            if (acode == 8) c1[i] = (int32_t)(a - b);
+            else if (acode == 9) c0[i] = (int32_t)(a + b);
+            else {
+                const long long side = b;
+                const long long sum = a * 2 + ((side < 0 ? -side : side) & 1);
+                c0[i] = (int32_t)((sum + side) >> 1);
+                c1[i] = (int32_t)((sum - side) >> 1);
+            }
+        }
+    }
+    if (!bad) {  // byte alignment + CRC-16 must end the frame exactly
+        r.pos = (r.pos + 7) & ~7ull;
+        if (r.pos + 16 != end_bit) bad = true;
+    }
+    if (bad) {
+        atomicAdd(&verify_counts[0], 1u);
+        return;
+    }
+    if (expect) {
+        const int32_t *e = expect + (size_t)frame * p.channels * p.ldb;
+        uint32_t diff = 0;
+        for (uint32_t c = 0; c < nch; c++)
+            for (uint32_t i = 0; i < n; i++) diff += rows[(size_t)c * p.ldb + i] != e[(size_t)c * p.ldb + i];
+        if (diff) {
+            atomicAdd(&verify_counts[2], 1u);
+            atomicAdd(&verify_counts[3], diff);
+        }
     }
 }
 
@@ -2360,6 +2582,8 @@ struct flacgpu_ctx {
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
     uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate)
+    int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
+    uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
@@ -2584,6 +2808,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_orbits);
+    (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -2857,7 +3082,7 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
         }
     }
     if (c->timing) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_crc, dim3(p.n_frames), dim3(WG), 0, st, p, q);
+    hipLaunchKernelGGL(k_crc<false>, dim3(p.n_frames), dim3(WG), 0, st, p, q, (uint32_t *)nullptr);
     if (c->timing) (void)hipEventRecord(ev[3], st);
     HIP_TRY(hipGetLastError());
     c->packed_valid = true;
@@ -2965,6 +3190,69 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
     if (compared) *compared = cmp;
     if (params_differ) *params_differ = diff;
     if (max_rel_err) *max_rel_err = worst;
+    return FLACGPU_OK;
+}
+
+int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_frame_number,
+                          flacgpu_verify_result *result, float *kernel_ms) {
+    if (!c || !c->packed_valid || !result) {
+        g_last_error = "flacgpu_verify_device: nothing packed";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    hipStream_t st = c->own_stream;
+    Params p = c->last_params;
+    const size_t F = c->max_frames, C = c->channels;
+    if (!c->d_decoded) {
+        HIP_TRY(hipMalloc((void **)&c->d_decoded, sizeof(int32_t) * (F * C * c->ldb + 64)));
+        HIP_TRY(hipMalloc((void **)&c->d_verify, sizeof(uint32_t) * 4));
+    }
+    PackParams q;
+    q.first_frame_number = first_frame_number;
+    q.sample_rate = sample_rate;
+    q.out_words = c->d_packed;
+    q.frame_off = c->d_frame_off;
+    q.cap_bytes = c->packed_cap;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * 4, st));
+    // compare against the planar PCM the analysis consumed, when it is the context's own copy
+    const int32_t *expect = (p.planar == c->d_planar && p.ldb == c->ldb) ? c->d_planar : nullptr;
+    Params pd = p;
+    pd.ldb = c->ldb;
+    (void)hipEventRecord(c->ev[0], st);
+    hipLaunchKernelGGL(k_decode, dim3((p.n_frames + 63) / 64), dim3(64), 0, st, pd, q, c->d_decoded,
+                       expect, c->d_verify);
+    hipLaunchKernelGGL(k_crc<true>, dim3(p.n_frames), dim3(WG), 0, st, p, q, c->d_verify);
+    (void)hipEventRecord(c->ev[1], st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    uint32_t counts[4];
+    HIP_TRY(hipMemcpy(counts, c->d_verify, sizeof counts, hipMemcpyDeviceToHost));
+    result->frames = p.n_frames;
+    result->bad_structure = counts[0];
+    result->bad_crc16 = counts[1];
+    result->frames_pcm_differs = counts[2];
+    result->samples_differ = counts[3];
+    result->compared_pcm = expect != nullptr;
+    if (kernel_ms) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        *kernel_ms = ms;
+    }
+    return FLACGPU_OK;
+}
+
+int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
+    if (!c || !c->d_decoded || !interleaved || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
+    const size_t F = c->last_frames, C = c->channels, B = c->opts.block_size, ldb = c->ldb;
+    std::vector<int32_t> planar(F * C * ldb);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(planar.data(), c->d_decoded, sizeof(int32_t) * planar.size(), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (size_t f = 0; f < F; f++) {
+        const size_t n = (f + 1 == F) ? c->last_len : B;
+        for (size_t i = 0; i < n; i++)
+            for (size_t ch = 0; ch < C; ch++) interleaved[o++] = planar[(f * C + ch) * ldb + i];
+    }
     return FLACGPU_OK;
 }
 

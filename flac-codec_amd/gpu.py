@@ -114,6 +114,28 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_encode_frames")
         return buf[: total.value].tobytes(), list(off)
 
+    def verify_device(self, sample_rate, first_frame_number=0):
+        """Decode the frames packed last on the GPU, check CRC-16 and compare with the analysed
+        PCM.  Returns (VerifyResult, kernel_ms)."""
+        res = _lib.VerifyResult()
+        ms = C.c_float(0)
+        rc = _lib.lib().flacgpu_verify_device(self._h, sample_rate, first_frame_number,
+                                              C.byref(res), C.byref(ms))
+        if rc:
+            raise GpuError(rc, "flacgpu_verify_device")
+        return res, ms.value
+
+    def fetch_decoded(self, n_frames, last_frame_len):
+        n = ((n_frames - 1) * self.block_size + last_frame_len) * self.channels
+        out = np.empty(n, dtype=np.int32)
+        rc = _lib.lib().flacgpu_fetch_decoded(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc:
+            raise GpuError(rc, "flacgpu_fetch_decoded")
+        return out
+
+    def device_buffer(self, which):
+        return _lib.lib().flacgpu_device_buffer(self._h, which)
+
     def experiment_mfma_autocorr(self):
         """EXPERIMENT (not on the product path): f64-MFMA autocorrelation of the last batch.
         Returns dict(ms, compared, params_differ, max_rel_err)."""

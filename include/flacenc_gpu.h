@@ -186,6 +186,27 @@ int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint
                           uint32_t sample_rate, uint8_t *out, size_t cap, uint64_t *offsets,
                           uint64_t *total);
 
+/* ---- device-side decode + verify of the frames packed last ----------
+ * The reference's frame decoder (decode.rs:1388-1436 read_frame, 1494-1633 read_subframes,
+ * 1635-1752 read_subframe / predict, 1800-1856 read_residuals) run on the GPU, one lane per
+ * frame, over the bytes produced by flacgpu_pack_device, plus a CRC-16 check of every frame.
+ * When the analysed PCM is still in the context (host-input or interleaved device input), the
+ * decoded samples are compared with it -- the round trip every encoder test of the reference
+ * performs (tests/format.rs), without leaving HBM. */
+typedef struct {
+    uint32_t frames;
+    uint32_t bad_structure;      /* header / CRC-8 / subframe structure errors */
+    uint32_t bad_crc16;
+    uint32_t frames_pcm_differs; /* only meaningful when compared_pcm != 0 */
+    uint32_t samples_differ;
+    uint32_t compared_pcm;
+} flacgpu_verify_result;
+int flacgpu_verify_device(flacgpu_ctx *ctx, uint32_t sample_rate, uint64_t first_frame_number,
+                          flacgpu_verify_result *result, float *kernel_ms);
+/* decoded PCM of the last flacgpu_verify_device, interleaved, to host memory
+ * ((n_frames-1)*block_size + last_frame_len) * channels samples */
+int flacgpu_fetch_decoded(flacgpu_ctx *ctx, int32_t *interleaved);
+
 /* EXPERIMENT, not on the product path: recomputes the autocorrelation of the last analysed
  * batch on the f64 matrix cores (v_mfma_f64_16x16x4_f64, block-Gram form), times that kernel,
  * reruns Levinson/quantisation on it and reports how many candidates' quantised LPC parameters
