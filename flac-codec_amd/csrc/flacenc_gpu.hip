@@ -218,6 +218,50 @@ struct RiceShared {
 };
 enum { PK_STANDARD = 0, PK_ESCAPED = 1, PK_CONSTANT = 2 };
 
+// Partition::new (encode.rs:3765-3831) for one partition of `cnt` residuals with sum of
+// absolute values `sum`: Rice parameter / escape decision and the size ESTIMATE the reference
+// ranks partition orders by.  The f64 `ceil(log2(sum / n))` of :3778-3780 is replaced by its
+// exact integer equivalent (smallest k with n * 2^k >= sum; sum < 2^53).
+struct PartEval {
+    uint32_t est;
+    uint8_t kind, rice, esc, bad;
+};
+__device__ __forceinline__ PartEval partition_eval(uint32_t cnt, unsigned long long sum,
+                                                   uint32_t rice_max) {
+    PartEval r;
+    r.est = 0;
+    r.kind = PK_CONSTANT;
+    r.rice = 0xFF;
+    r.esc = 0;
+    r.bad = 0;
+    if (cnt > 0 && sum > 0) {
+        uint32_t k = 0;
+        bool standard = true;
+        if (sum > (unsigned long long)cnt) {
+            const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
+            const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
+            k = bs > bc ? bs - bc - 1 : 0;
+            while (((unsigned long long)cnt << k) < sum) k++;
+            if (k >= rice_max) {
+                standard = false;
+                const uint32_t e = (bs - 1) + 2u;  // ilog2(sum) + 2
+                if (e > 31u) r.bad = 1;
+                r.kind = PK_ESCAPED;
+                r.esc = (uint8_t)e;
+                r.est = e * cnt;
+            }
+        }
+        if (standard) {
+            const unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
+            if (t > 0xFFFFFFFFull) r.bad = 1;  // u32::try_from fails -> candidate dropped
+            r.kind = PK_STANDARD;
+            r.rice = (uint8_t)k;
+            r.est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
+        }
+    }
+    return r;
+}
+
 __device__ __forceinline__ uint32_t rice_levels(uint32_t n, const Params &p) {
     uint32_t tz = (uint32_t)__builtin_ctz(n);
     uint32_t P = tz < p.max_po ? tz : p.max_po;
@@ -274,33 +318,9 @@ __device__ __forceinline__ void rice_tree(RiceShared &S, uint32_t n, uint32_t or
             const uint32_t plen = n >> lvl;
             const uint32_t start = j * plen, end = start + plen;
             const uint32_t cnt = (end > order) ? end - (start > order ? start : order) : 0u;
-            uint8_t kind = PK_CONSTANT, rice = 0xFF, esc = 0;
-            uint32_t est = 0, bad = 0;
-            if (cnt > 0 && sum > 0) {
-                uint32_t k = 0;
-                bool standard = true;
-                if (sum > (unsigned long long)cnt) {
-                    const uint32_t bs = 64u - (uint32_t)__clzll((long long)sum);
-                    const uint32_t bc = 32u - (uint32_t)__builtin_clz(cnt);
-                    k = bs > bc ? bs - bc - 1 : 0;
-                    while (((unsigned long long)cnt << k) < sum) k++;
-                    if (k >= rice_max) {
-                        standard = false;
-                        const uint32_t e = (bs - 1) + 2u;  // ilog2(sum) + 2
-                        if (e > 31u) bad = 1;
-                        kind = PK_ESCAPED;
-                        esc = (uint8_t)e;
-                        est = e * cnt;
-                    }
-                }
-                if (standard) {
-                    const unsigned long long t = k ? (sum >> (k - 1)) : (sum << 1);
-                    if (t > 0xFFFFFFFFull) bad = 1;  // u32::try_from fails -> candidate dropped
-                    kind = PK_STANDARD;
-                    rice = (uint8_t)k;
-                    est = 4u + (1u + k) * cnt + (uint32_t)t - cnt / 2u;  // wrapping u32
-                }
-            }
+            const PartEval pe = partition_eval(cnt, sum, rice_max);
+            const uint8_t kind = pe.kind, rice = pe.rice, esc = pe.esc;
+            const uint32_t est = pe.est, bad = pe.bad;
             S.nd_kind[node] = kind;
             S.nd_rice[node] = rice;
             S.nd_esc[node] = esc;
@@ -1561,7 +1581,7 @@ __device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[PW], const int32_t
         for (int j = 0; j < T; j++) sum += (long long)pw[O + e - 1 - j] * (long long)c[j];
         const int32_t pred = (int32_t)(sum >> shift);
         const long long d = (long long)pw[O + e] - (long long)pred;
-        if ((uint32_t)e >= first && (d < INT32_MIN || d > INT32_MAX)) ovf = 1;  // ResidualOverflow
+        if ((e >= 16 || (uint32_t)e >= first) && (d < INT32_MIN || d > INT32_MAX)) ovf = 1;  // ResidualOverflow
         res[e] = (int32_t)d;
     }
     return ovf;
@@ -1688,6 +1708,393 @@ __global__ void __launch_bounds__(WG) k_fir16(Params p) {
         uint32_t *d = reinterpret_cast<uint32_t *>(p.cand_plan + cidx);
         for (uint32_t i = tid; i < sizeof(SubPlan) / 4; i += WG) d[i] = s[i];
     }
+}
+
+// =================================================================================
+// Wave-per-candidate kernel for blocks of exactly 4096 samples (candidates <= 25 bits, LPC
+// order <= 16): ONE wave64 does the whole FIXED + LPC analysis of one candidate.  Lane l owns
+// samples [64 l, 64 l + 64) in registers, which is exactly one finest Rice partition, so the
+// partition tree needs no atomics; neighbours come through wave shuffles; there is NO workgroup
+// barrier in the kernel (the 4 waves of a workgroup are the 4 candidates of a frame and share
+// L1/L2).  Same decisions as k_fixed16 + k_fir16 (same helpers), about 40 % fewer instructions.
+// =================================================================================
+struct WaveRice {
+    uint32_t bits;      // residual block bits (method + order + partitions)
+    bool ok;            // false: the 31-bit fallback partition cannot hold a residual
+    int bp;             // chosen partition level, -1 = 31-bit escaped fallback
+    uint32_t count, method;
+    uint8_t price, pesc;  // parameters of partition `lane` (valid for lane < count)
+};
+
+// v + (v moved across lanes by one DPP control); lanes without a source lane add 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+// inclusive prefix sum over the 64 lanes (wrapping u32), six DPP adds and no LDS traffic:
+// row_shr 1/2/4/8 scan each row of 16, row_bcast:15 / :31 carry the row totals forward
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v = dpp_add<0x111>(v);
+    v = dpp_add<0x112>(v);
+    v = dpp_add<0x114>(v);
+    v = dpp_add<0x118>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_u32(v), 63);
+}
+// total of per-lane values < 2^48 (two u32 limbs)
+__device__ __forceinline__ uint64_t wave_total_u48(uint64_t v) {
+    const uint32_t lo = wave_total_u32((uint32_t)v & 0xFFFFFFu);
+    const uint32_t hi = wave_total_u32((uint32_t)(v >> 24));
+    return ((uint64_t)hi << 24) + lo;
+}
+// the previous lane's value, 0 on lane 0 (wave_shr:1)
+__device__ __forceinline__ int32_t lane_prev(int32_t v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t sread(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// Rice search of one wave's residual (encode.rs:3862-3947), lane l = samples [64 l, 64 l + 64).
+// `res` is consumed: warm-up entries (lane 0, e < order <= MAXORD) are zeroed and every value
+// is folded to t = r ^ (r >> 31) = zigzag(r) >> 1, so that
+//   sum |r| = sum t + #negative,  zigzag(r) >> k = t >> (k - 1) for k >= 1,
+//   sum zigzag(r) = 2 sum t + #negative.
+// Level totals come from one DPP scan of the node estimates plus ballots; nothing touches LDS.
+template <int MAXORD>
+__device__ __forceinline__ WaveRice wave_rice(int32_t (&res)[64], uint32_t order, const Params &p) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t P = rice_levels(FN, p);
+    const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
+    const uint32_t first = lane == 0 ? order : 0u;
+#pragma unroll
+    for (int e = 0; e < MAXORD; e++) res[e] = (uint32_t)e >= first ? res[e] : 0;
+    uint64_t sum_t = 0;
+    uint32_t neg = 0;
+#pragma unroll
+    for (int e = 0; e < 64; e += 2) {
+        const int32_t s0 = res[e] >> 31, s1 = res[e + 1] >> 31;
+        res[e] ^= s0;
+        res[e + 1] ^= s1;
+        neg -= (uint32_t)s0;
+        neg -= (uint32_t)s1;
+        sum_t += (uint32_t)res[e] + (uint32_t)res[e + 1];  // each < 2^31
+    }
+    const uint64_t mysum = sum_t + neg;  // sum |r| of this lane's 64 samples, < 2^37
+    // inclusive prefix of the leaf sums in two limbs
+    const uint32_t sc_lo = wave_scan_u32((uint32_t)mysum & 0xFFFFFu);
+    const uint32_t sc_hi = wave_scan_u32((uint32_t)(mysum >> 20));
+    const uint64_t incl = ((uint64_t)sc_hi << 20) + sc_lo;
+    // leaf node 64 + lane (level 6) and internal node `lane` (levels 0..5), heap numbering
+    const uint32_t leaf_cnt = 64u - first;
+    const PartEval le = partition_eval(leaf_cnt, mysum, rice_max);
+    const uint32_t node = lane;
+    const uint32_t lvl = node ? 31u - (uint32_t)__builtin_clz(node) : 0u;
+    const uint32_t j = node - (1u << lvl);
+    const uint32_t span = 64u >> lvl;
+    const uint32_t hi = (j + 1) * span - 1, lo = j * span;
+    const uint64_t top = __shfl(incl, (int)(hi & 63), 64);
+    const uint64_t bot = __shfl(incl, (int)((lo ? lo - 1 : 0) & 63), 64);
+    const uint64_t isum = top - (lo ? bot : 0ull);
+    const uint32_t plen = FN >> lvl;
+    const uint32_t istart = j * plen, iend = istart + plen;
+    const uint32_t icnt = (node && iend > order) ? iend - (istart > order ? istart : order) : 0u;
+    const PartEval ie = partition_eval(icnt, isum, rice_max);
+    // per-level aggregates: estimate sums from a scan over the node lanes, the rest from ballots
+    const uint32_t esc = wave_scan_u32(icnt ? ie.est : 0u);
+    const uint64_t m_cnt = __ballot(icnt > 0);
+    const uint64_t m_bad = __ballot(icnt > 0 && ie.bad);
+    const uint64_t m_hi = __ballot(icnt > 0 && ie.kind == PK_STANDARD && ie.rice >= 15);
+    WaveRice w;
+    w.bp = -1;
+    uint32_t best_est = 0, best_cnt = 1, best_hi = 0;
+#pragma unroll
+    for (uint32_t l = 0; l <= 6; l++) {
+        if (l > P) break;
+        uint32_t est, c;
+        bool bad, hi15;
+        if (l < 6) {
+            const uint64_t lm = ((1ull << (1u << l)) - 1ull) << (1u << l);  // lanes 2^l .. 2^(l+1)-1
+            est = sread(esc, (2 << l) - 1) - sread(esc, (1 << l) - 1);
+            c = (uint32_t)__popcll(m_cnt & lm);
+            bad = (m_bad & lm) != 0;
+            hi15 = (m_hi & lm) != 0;
+        } else {
+            est = wave_total_u32(leaf_cnt ? le.est : 0u);
+            c = (uint32_t)__popcll(__ballot(leaf_cnt > 0));
+            bad = __ballot(leaf_cnt > 0 && le.bad) != 0;
+            hi15 = __ballot(leaf_cnt > 0 && le.kind == PK_STANDARD && le.rice >= 15) != 0;
+        }
+        // `!p.is_empty() && p.len().is_power_of_two()` (encode.rs:3881), first minimum (:3885)
+        const bool ok = !bad && c > 0 && (c & (c - 1)) == 0;
+        if (ok && (w.bp < 0 || est < best_est)) {
+            w.bp = (int)l;
+            best_est = est;
+            best_cnt = c;
+            best_hi = hi15 ? 1u : 0u;
+        }
+    }
+    w.count = best_cnt;
+    w.method = (w.bp >= 0 && p.use_rice2 && best_hi) ? 1u : 0u;  // try_reduce_rice, :3929-3942
+    const uint32_t hb = w.method ? 5u : 4u;
+    // packed evaluation records to pass between lanes: cnt | kind << 16 | rice << 18 | esc << 26
+    const uint32_t lrec = leaf_cnt | ((uint32_t)le.kind << 16) | ((uint32_t)le.rice << 18) | ((uint32_t)le.esc << 26);
+    const uint32_t irec = icnt | ((uint32_t)ie.kind << 16) | ((uint32_t)ie.rice << 18) | ((uint32_t)ie.esc << 26);
+    uint32_t mine = 0;  // bits, wrapping u32 like the reference's counter
+    w.price = 0;
+    w.pesc = 0;
+    bool wide = false;
+    if (w.bp >= 0) {
+        const uint32_t bp = (uint32_t)w.bp;
+        const uint32_t first_j = (1u << bp) - w.count;
+        // partition q = lane of the chosen level: its record lives on lane first_j + q (leaf
+        // level) or on lane 2^bp + first_j + q (internal node)
+        const uint32_t qsrc = bp == 6 ? first_j + lane : (1u << bp) + first_j + lane;
+        const uint32_t qrec = __shfl(bp == 6 ? lrec : irec, (int)(qsrc & 63), 64);
+        if (lane < w.count) {
+            const uint32_t c = qrec & 0xFFFF, kind = (qrec >> 16) & 3, rice = (qrec >> 18) & 0xFF, esc2 = qrec >> 26;
+            w.price = (uint8_t)rice;
+            w.pesc = (uint8_t)esc2;
+            if (kind == PK_STANDARD) mine += hb + (1u + rice) * c;
+            else if (kind == PK_ESCAPED) mine += hb + 5u + esc2 * c;
+            else mine += hb + 5u;
+        }
+        // Rice parameter of the partition this lane's 64 samples fall in
+        const uint32_t msrc = (1u << bp) + (lane >> (6 - bp));
+        const uint32_t mrec = bp == 6 ? lrec : (uint32_t)__shfl(irec, (int)(msrc & 63), 64);
+        const uint32_t k = (mrec >> 18) & 0xFF;
+        const uint32_t sh = (k == 0 || k == 0xFF) ? 0u : k - 1u;
+        uint32_t q = 0;
+#pragma unroll
+        for (int e = 0; e < 64; e++) q += (uint32_t)res[e] >> sh;
+        mine += k == 0xFF ? 0u : k == 0 ? 2u * (uint32_t)sum_t + neg : q;
+    } else {
+        if (lane == 0) {
+            w.price = 0xFF;
+            w.pesc = 31;  // one escaped 31-bit partition, encode.rs:3887-3895
+            mine += 4u + 5u + 31u * (FN - order);
+        }
+        // t >= 2^30  <=>  r outside [-2^30, 2^30): write_signed_counted(31) fails (:3857)
+#pragma unroll
+        for (int e = 0; e < 64; e++) wide |= (uint32_t)res[e] >= (1u << 30);
+    }
+    w.bits = 6u + wave_total_u32(mine);  // method (2) + partition order (4), :3949, :3902
+    w.ok = !__any(wide);
+    return w;
+}
+
+// FIR of one lane's 64 samples, IN PLACE and descending (x[e] is dead once its residual exists);
+// hp[16] = the 16 samples before them (zeros for lane 0); coefficients are wave-uniform.
+// Returns the sign-bit OR of every i32 subtraction overflow outside the warm-up
+// (ResidualOverflow, encode.rs:3190-3197).
+template <int T>
+__device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[16],
+                                          const int32_t *__restrict__ qlp, uint32_t order,
+                                          uint32_t shift) {
+    int32_t c[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? __builtin_amdgcn_readfirstlane(qlp[j]) : 0;
+    // bit e set: sample e of this lane is warm-up (lane 0 only)
+    const uint32_t warm = (threadIdx.x & 63) == 0 ? ((1u << order) - 1u) : 0u;
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int e = 63; e >= 0; e--) {
+        long long sum = 0;
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            const int i = e - 1 - j;
+            const int32_t v = i >= 0 ? x[i >= 0 ? i : 0] : hp[i >= 0 ? 0 : 16 + i];
+            sum += (long long)v * (long long)c[j];
+        }
+        const int32_t pred = (int32_t)(sum >> shift);
+        const int32_t d = (int32_t)((uint32_t)x[e] - (uint32_t)pred);
+        uint32_t o = (uint32_t)(x[e] ^ pred) & (uint32_t)(x[e] ^ d);  // sign bit: x - pred overflowed
+        if (e < 16) o &= ~(warm << (31 - e));
+        ovf |= o;
+        x[e] = d;
+    }
+    return ovf >> 31;
+}
+
+// residual of fixed order K from the lane's samples and the 4 before them (encode.rs:3039-3060)
+template <int K>
+__device__ __forceinline__ void fixed64(const int32_t (&x)[64], const int32_t (&h)[4], int32_t (&res)[64]) {
+    int32_t q0 = h[3], q1 = h[3] - h[2], q2 = (h[3] - h[2]) - (h[2] - h[1]);
+    int32_t q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
+#pragma unroll
+    for (int e = 0; e < 64; e++) {
+        const int32_t d1 = x[e] - q0, d2 = d1 - q1, d3 = d2 - q2, d4 = d3 - q3;
+        res[e] = K == 0 ? x[e] : K == 1 ? d1 : K == 2 ? d2 : K == 3 ? d3 : d4;
+        q0 = x[e]; q1 = d1; q2 = d2; q3 = d3;
+    }
+}
+
+__device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uint32_t wasted,
+                                                uint32_t bps, uint32_t order, uint32_t precision,
+                                                uint32_t shift, uint32_t source, uint32_t bits,
+                                                const WaveRice *w, const int32_t *qlp) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    if (lane == 0) {
+        const uint32_t method = w ? w->method : 0u;
+        const uint32_t count = w ? w->count : 0u;
+        const uint32_t porder = count ? 31u - (uint32_t)__builtin_clz(count) : 0u;
+        d[0] = type | (wasted << 8) | (bps << 16) | (order << 24);
+        d[1] = precision | (shift << 8) | (method << 16) | (porder << 24);
+        d[2] = source;                                       // source, reserved[3]
+        d[3] = count;                                        // n_partitions
+        d[4] = w ? (w->bp >= 0 ? FN >> w->bp : FN) : 0u;     // part_len
+        d[5] = bits;
+    }
+    if (lane < 32) d[6 + lane] = (qlp && lane < order) ? (uint32_t)qlp[lane] : 0u;  // coeffs
+    uint8_t *b = reinterpret_cast<uint8_t *>(dst);
+    const bool live = w && lane < w->count;
+    b[24 + 128 + lane] = live ? w->price : 0;        // rice[lane]
+    b[24 + 128 + 64 + lane] = live ? w->pesc : 0;    // escape_bits[lane]
+}
+
+__global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t local = blockIdx.x * 4 + wave;
+    if (local >= p.fcount * p.ncand) return;
+    const uint32_t frame = p.f0 + local / p.ncand, cand = local % p.ncand;
+    const size_t cidx = (size_t)frame * p.ncand + cand;
+    const CandInfo ci = p.cinfo[cidx];
+    if (!ci.active) return;
+    const CandSrc src = cand_src(p, frame, cand);
+    SubPlan *out = p.cand_plan + cidx;
+    if (ci.is_const) {  // all zero -> CONSTANT(0) at the candidate's bps (encode.rs:2883-2887)
+        store_plan_wave(out, FLACGPU_SUB_CONSTANT, 0, src.bps, 0, 0, 0, src.source, 8u + src.bps, nullptr, nullptr);
+        return;
+    }
+    const uint32_t wasted = __builtin_amdgcn_readfirstlane((uint32_t)ci.wasted);
+    const uint32_t bps_eff = __builtin_amdgcn_readfirstlane((uint32_t)ci.bps);
+    int32_t x[64];
+    {
+        const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 16 * lane;
+        const int4 *pb = reinterpret_cast<const int4 *>(src.b) + 16 * lane;
+        if (src.mode == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int4 a = pa[q];
+                x[4 * q] = a.x >> wasted; x[4 * q + 1] = a.y >> wasted;
+                x[4 * q + 2] = a.z >> wasted; x[4 * q + 3] = a.w >> wasted;
+            }
+        } else if (src.mode == 1) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int4 a = pa[q], b = pb[q];
+                x[4 * q] = combine(1, a.x, b.x) >> wasted; x[4 * q + 1] = combine(1, a.y, b.y) >> wasted;
+                x[4 * q + 2] = combine(1, a.z, b.z) >> wasted; x[4 * q + 3] = combine(1, a.w, b.w) >> wasted;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int4 a = pa[q], b = pb[q];
+                x[4 * q] = combine(2, a.x, b.x) >> wasted; x[4 * q + 1] = combine(2, a.y, b.y) >> wasted;
+                x[4 * q + 2] = combine(2, a.z, b.z) >> wasted; x[4 * q + 3] = combine(2, a.w, b.w) >> wasted;
+            }
+        }
+    }
+    // the previous lane's last 4 samples (zeros before the block start)
+    int32_t h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = lane_prev(x[60 + k]);
+    // ---- FIXED: abs sums of the iterated differences over [4, n) (encode.rs:3039-3073).
+    // Values are biased by 2^30 (unsigned), |a - b| + acc is one v_sad_u32; u32 partial sums are
+    // flushed every 8 terms (|d4| < 2^28 for <= 25-bit candidates).
+    constexpr uint32_t BIAS = 1u << 30;
+    uint64_t sm[5] = {0, 0, 0, 0, 0};
+    {
+        const uint32_t hb0 = (uint32_t)h[0] + BIAS, hb1 = (uint32_t)h[1] + BIAS, hb2 = (uint32_t)h[2] + BIAS,
+                       hb3 = (uint32_t)h[3] + BIAS;
+        const uint32_t d1m3 = hb1 - hb0 + BIAS, d1m2 = hb2 - hb1 + BIAS, d1m1 = hb3 - hb2 + BIAS;
+        const uint32_t d2m2 = d1m2 - d1m3 + BIAS, d2m1 = d1m1 - d1m2 + BIAS;
+        uint32_t p0 = hb3, p1 = d1m1, p2 = d2m1, p3 = d2m1 - d2m2 + BIAS;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;  // contributions of samples 0..3
+#pragma unroll
+        for (int e = 0; e < 64; e++) {
+            const uint32_t xb = (uint32_t)x[e] + BIAS;
+            const uint32_t d1 = xb - p0 + BIAS, d2 = d1 - p1 + BIAS, d3 = d2 - p2 + BIAS;
+            a0 = __usad(xb, BIAS, a0);
+            a1 = __usad(xb, p0, a1);
+            a2 = __usad(d1, p1, a2);
+            a3 = __usad(d2, p2, a3);
+            a4 = __usad(d3, p3, a4);
+            p0 = xb; p1 = d1; p2 = d2; p3 = d3;
+            if (e == 3) { c0 = a0; c1 = a1; c2 = a2; c3 = a3; c4 = a4; }
+            if ((e & 7) == 7) {
+                sm[0] += a0; sm[1] += a1; sm[2] += a2; sm[3] += a3; sm[4] += a4;
+                a0 = a1 = a2 = a3 = a4 = 0;
+            }
+        }
+        if (lane == 0) { sm[0] -= c0; sm[1] -= c1; sm[2] -= c2; sm[3] -= c3; sm[4] -= c4; }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) sm[k] = wave_total_u48(sm[k]);
+    uint32_t forder = 0;
+#pragma unroll
+    for (uint32_t k = 1; k <= 4; k++)
+        if (sm[k] < sm[forder]) forder = k;  // min_by_key: first minimum wins
+    int32_t res[64];
+    switch (forder) {
+    case 0: fixed64<0>(x, h, res); break;
+    case 1: fixed64<1>(x, h, res); break;
+    case 2: fixed64<2>(x, h, res); break;
+    case 3: fixed64<3>(x, h, res); break;
+    default: fixed64<4>(x, h, res); break;
+    }
+    const WaveRice fw = wave_rice<4>(res, forder, p);
+    const uint32_t fixed_bits = 8u + wasted + forder * bps_eff + fw.bits;
+    const bool fixed_ok = fw.ok;
+    // ---- LPC (encode.rs:3174-3203 + the same residual coding)
+    bool lpc_ok = false;
+    uint32_t lpc_bits = 0;
+    WaveRice lw = fw;
+    const LpcParams *lp = p.lpc + cidx;
+    uint32_t lorder = 0;
+    if (p.max_lpc_order > 0 && lp->status == 0) {
+        lorder = __builtin_amdgcn_readfirstlane((uint32_t)lp->order);
+        const uint32_t shift = __builtin_amdgcn_readfirstlane((uint32_t)lp->shift);
+        int32_t hp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) hp[k] = lane_prev(x[48 + k]);
+        uint32_t ovf;
+        switch ((lorder + 3) >> 2) {
+        case 1: ovf = fir64<4>(x, hp, lp->qlp, lorder, shift); break;
+        case 2: ovf = fir64<8>(x, hp, lp->qlp, lorder, shift); break;
+        case 3: ovf = fir64<12>(x, hp, lp->qlp, lorder, shift); break;
+        default: ovf = fir64<16>(x, hp, lp->qlp, lorder, shift); break;
+        }
+        if (__any(ovf)) {
+            if (lane == 0) atomicAdd(&p.stats[0], 1u);
+        } else {
+            lw = wave_rice<16>(x, lorder, p);
+            lpc_ok = lw.ok;
+            if (!lpc_ok && lane == 0) atomicAdd(&p.stats[0], 1u);
+            lpc_bits = 8u + wasted + lorder * bps_eff + 4u + 5u + lorder * lp->precision + lw.bits;
+        }
+    }
+    // (Ok,Ok) -> min_by_key(written) with FIXED first; (Err,Ok) -> LPC; (Ok,Err) -> FIXED;
+    // (Err,Err) -> VERBATIM; then the verbatim threshold (encode.rs:2929-2979)
+    const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);
+    const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
+    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < FN * bps_eff);
+    if (verbatim)
+        store_plan_wave(out, FLACGPU_SUB_VERBATIM, wasted, bps_eff, 0, 0, 0, src.source,
+                        8u + wasted + FN * bps_eff, nullptr, nullptr);
+    else if (use_lpc)
+        store_plan_wave(out, FLACGPU_SUB_LPC, wasted, bps_eff, lorder, lp->precision, lp->shift,
+                        src.source, lpc_bits, &lw, lp->qlp);
+    else
+        store_plan_wave(out, FLACGPU_SUB_FIXED, wasted, bps_eff, forder, 0, 0, src.source, fixed_bits,
+                        &fw, nullptr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2564,7 +2971,7 @@ __global__ void __launch_bounds__(64) k_decode(Params p, PackParams q, int32_t *
 const char *const kKernelNames[FLACGPU_N_KERNELS] = {
     "k_deinterleave", "k_stereo_stats", "k_fixed", "k_autocorr", "k_lpc",
     "k_fir",          "k_decide",       "k_emit",  "k_layout",   "k_pack",
-    "k_crc",          "(unused)"};
+    "k_crc",          "k_cand64"};
 
 }  // namespace
 
@@ -2931,19 +3338,21 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = n_frames - n_fast;
-    // The FIXED analysis and the autocorrelation -> Levinson chain only share their input, so
-    // they run concurrently on two HIP streams (fork after k_candinfo, join before k_fir); the
-    // FIXED kernels are integer-VALU bound, the autocorrelation f64-VALU/LDS bound.  With
-    // per-kernel timing enabled everything is serialised on one stream.
     const bool lpc = p.max_lpc_order > 0;
-    const bool fork = lpc && !c->timing && !getenv("FLACGPU_NO_FORK");
+    // frames on the register path with LPC order <= 16 take the wave-per-candidate kernel
+    // (FIXED + LPC analysis of a candidate in one wave, after the LPC parameters are known)
+    const bool w64 = n_fast && p.max_lpc_order <= 16 && p.max_po <= 6 && !getenv("FLACGPU_NO_W64");
+    // Otherwise the FIXED analysis and the autocorrelation -> Levinson chain, which only share
+    // their input, run concurrently on two HIP streams (fork after k_candinfo, join before
+    // k_fir).  With per-kernel timing enabled everything is serialised on one stream.
+    const bool fork = lpc && !c->timing && !getenv("FLACGPU_NO_FORK") && !(w64 && pg.fcount == 0);
     hipStream_t sf = fork ? c->aux_stream : st;
     if (fork) {
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(sf, c->ev_fork, 0));
     }
     begin(2);
-    if (pf.fcount) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, sf, pf);
+    if (pf.fcount && !w64) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, sf, pf);
     if (pg.fcount) hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, sf, pg);
     if (fork) HIP_TRY(hipEventRecord(c->ev_join, sf));
     if (lpc) {
@@ -2956,13 +3365,17 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         begin(5);
-        if (pf.fcount) {
+        if (pf.fcount && !w64) {
             if (p.max_lpc_order <= 16)
                 hipLaunchKernelGGL(k_fir16<1>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
             else
                 hipLaunchKernelGGL(k_fir16<2>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
         }
         if (pg.fcount) hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
+    }
+    if (w64) {
+        begin(11);
+        hipLaunchKernelGGL(k_cand64, dim3((pf.fcount * c->ncand + 3) / 4), dim3(WG), 0, st, pf);
     }
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
