@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "flacenc_gpu.h"
@@ -843,93 +844,210 @@ __global__ void __launch_bounds__(WG) k_fixed(Params p) {
 // ---------------------------------------------------------------------------------
 constexpr int AC_LD = 36;  // row stride of the ac buffer (max H)
 
-template <int H, int A, int LG, bool FIRST, bool GUARDED>
-__device__ __forceinline__ void ac_block(double (&hist)[H], double (&acc)[LG], const int32_t *pa,
-                                         const int32_t *pb, int mode, uint32_t wasted,
-                                         const double *__restrict__ win, uint32_t base, uint32_t n) {
-    int32_t xa[H], xb[H];
-    if (GUARDED) {  // first / last block: element loads that never touch memory past the row
+// ---------------------------------------------------------------------------------
+// K3 for stereo frames (L, R, mid, side candidates) whose length is a multiple of 32, lags <= 16,
+// samples <= 24 bits: every wave is self-contained -- no workgroup barrier at all.
+//   lane = candidate (16 frames x 4 candidates per wave), wave pairs/quads split the lags.
+//   The wave stages the raw L/R rows of its 16 frames through a private, double-buffered LDS
+//   tile (32 rows x 32 samples), each lane reads its two source rows 16 samples at a time
+//   (ds_read_b128), forms (a + cb * b) >> sh (one v_mad_i32_i24 + one shift covers L, R,
+//   mid and side), converts to f64, multiplies by the window (wave-uniform, scalar loads) and
+//   accumulates its lags strictly in sample order (the reference's left fold per lag,
+//   encode.rs:3403-3413).  History is the previous 16-sample block, kept in registers and
+//   statically indexed (the loop is unrolled over two blocks).
+// ---------------------------------------------------------------------------------
+constexpr int AC3_TS = 32;            // samples per tile
+constexpr int AC3_LD = AC3_TS + 4;    // int row stride: 16-byte aligned, rows spread over banks
+constexpr int AC3_ROWS = 32;          // 16 frames x (L, R)
+
+template <int A, int LG, bool FIRST>
+__device__ __forceinline__ void ac3_block(const double (&w)[16], const double (&prev)[16],
+                                          double (&acc)[LG]) {
 #pragma unroll
-        for (int s = 0; s < H; s++) {
-            const bool in = base + s < n;
-            xa[s] = in ? pa[base + s] : 0;
-            xb[s] = in ? pb[base + s] : 0;
-        }
-    } else {
+    for (int s = 0; s < 16; s++) {
+        // all products of a sample first, then the adds: a dependent f64 pair issued back to
+        // back stalls the wave (7.3 instead of 5 cycles per instruction with one wave per SIMD)
+        double prod[LG];
 #pragma unroll
-        for (int q = 0; q < H / 4; q++) {
-            const int4 va = *reinterpret_cast<const int4 *>(pa + base + 4 * q);
-            const int4 vb = *reinterpret_cast<const int4 *>(pb + base + 4 * q);
-            xa[4 * q] = va.x; xa[4 * q + 1] = va.y; xa[4 * q + 2] = va.z; xa[4 * q + 3] = va.w;
-            xb[4 * q] = vb.x; xb[4 * q + 1] = vb.y; xb[4 * q + 2] = vb.z; xb[4 * q + 3] = vb.w;
+        for (int k = 0; k < LG; k++) {
+            const int lag = A + k;
+            const double o = (s - lag >= 0) ? w[(s - lag >= 0) ? s - lag : 0]
+                                            : prev[(s - lag >= 0) ? 0 : 16 + s - lag];
+            prod[k] = w[s] * o;
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < LG; k++) {
+            const int lag = A + k;
+            if (FIRST && s < lag) continue;  // i >= lag only (first block of the frame)
+            acc[k] = acc[k] + prod[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// raw operands of one 16-sample block: the lane's two source rows + the window slice
+struct Ac3Raw {
+    int4 a[4], b[4];
+    double2 w[8];
+};
+__device__ __forceinline__ void ac3_load(const int32_t *ra, const int32_t *rb, const double *wt,
+                                         uint32_t col, Ac3Raw &r) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        r.a[q] = *reinterpret_cast<const int4 *>(ra + col + 4 * q);
+        r.b[q] = *reinterpret_cast<const int4 *>(rb + col + 4 * q);
     }
 #pragma unroll
-    for (int s = 0; s < H; s++) {
-        const int32_t v = combine(mode, xa[s], xb[s]) >> wasted;
-        const double w = (double)v * win[base + s];  // Window::apply, encode.rs:1799
-        hist[s] = w;
-        if (!GUARDED || base + s < n) {
+    for (int q = 0; q < 8; q++) r.w[q] = *reinterpret_cast<const double2 *>(wt + col + 2 * q);  // broadcast
+}
+__device__ __forceinline__ void ac3_convert(const Ac3Raw &r, int32_t cb, uint32_t sh, double (&w)[16]) {
 #pragma unroll
-            for (int k = 0; k < LG; k++) {
-                const int lag = A + k;
-                if (!FIRST || s >= lag) {
-                    const double prod = w * hist[(s - lag + 2 * H) % H];
-                    acc[k] = acc[k] + prod;
-                }
-            }
+    for (int q = 0; q < 4; q++) {
+        const int32_t a[4] = {r.a[q].x, r.a[q].y, r.a[q].z, r.a[q].w};
+        const int32_t b[4] = {r.b[q].x, r.b[q].y, r.b[q].z, r.b[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int s = 4 * q + e;
+            const int32_t v = (__mul24(b[e], cb) + a[e]) >> sh;
+            const double win = (s & 1) ? r.w[s >> 1].y : r.w[s >> 1].x;
+            w[s] = (double)v * win;
         }
     }
 }
 
-template <int H, int A, int LG>
-__device__ __forceinline__ void ac_body(const Params &p, uint32_t frame0, uint32_t nframes,
-                                        uint32_t n, const double *__restrict__ win) {
-    const uint32_t lane_cand = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t total = nframes * p.ncand;
-    const bool live = lane_cand < total;
-    const uint32_t cc = live ? lane_cand : 0;
-    const uint32_t frame = frame0 + cc / p.ncand;
-    const uint32_t cand = cc % p.ncand;
-    const CandSrc src = cand_src(p, frame, cand);
-    const CandInfo ci = p.cinfo[(size_t)frame * p.ncand + cand];
-    const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
 
-    double hist[H], acc[LG];
+// per-lane constants + staging registers of one wave
+struct Ac3Lane {
+    const int32_t *gsrc[4];   // global source of this lane's 4 staged int4 (tile 0)
+    const double *wsrc;       // window slice source (2 f64 per lane of each 16-lane group)
+    uint32_t sdst[4];         // LDS destinations (ints, within a buffer)
+    uint32_t wdst;
+    uint32_t off_a, off_b;    // LDS offsets of the candidate's two source rows
+    int32_t cb;
+    uint32_t sh;
+    uint32_t ntiles;
+    int4 stage[4];
+    double2 wstage;
+};
+__device__ __forceinline__ void ac3_fetch(Ac3Lane &L, uint32_t t) {
+    t = t < L.ntiles ? t : L.ntiles - 1;
+#pragma unroll
+    for (int it = 0; it < 4; it++) L.stage[it] = *reinterpret_cast<const int4 *>(L.gsrc[it] + t * AC3_TS);
+    L.wstage = *reinterpret_cast<const double2 *>(L.wsrc + t * AC3_TS);
+}
+__device__ __forceinline__ void ac3_commit(const Ac3Lane &L, int32_t *dst) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) *reinterpret_cast<int4 *>(dst + L.sdst[it]) = L.stage[it];
+    *reinterpret_cast<double2 *>(dst + L.wdst) = L.wstage;
+}
+__device__ __forceinline__ void ac3_sync() {  // LDS operations of one wave execute in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+constexpr int AC3_RAW = AC3_ROWS * AC3_LD;       // ints of raw rows per buffer
+constexpr int AC3_BUF = AC3_RAW + 2 * AC3_TS;    // + the window slice (f64)
+
+// Software pipeline per tile of 32 samples (two blocks of 16):
+//   block 0: prefetch block 1's operands from LDS, convert + accumulate block 0
+//   block 1: commit tile t+1 (fetched one whole tile ago) into the other buffer, start the
+//            global fetch of tile t+2, prefetch the next tile's block 0, accumulate block 1
+template <int A, int LG, bool FIRST>
+__device__ __forceinline__ void ac3_tile(Ac3Lane &L, int32_t *tile, uint32_t t, Ac3Raw &r0, Ac3Raw &r1,
+                                         double (&w0)[16], double (&w1)[16], double (&acc)[LG]) {
+    const uint32_t buf = t & 1;
+    int32_t *cur = tile + buf * AC3_BUF, *nxt = tile + (buf ^ 1) * AC3_BUF;
+    ac3_load(cur + L.off_a, cur + L.off_b, reinterpret_cast<const double *>(cur + AC3_RAW), 16, r1);
+    __builtin_amdgcn_sched_barrier(0);
+    ac3_convert(r0, L.cb, L.sh, w0);
+    ac3_block<A, LG, FIRST>(w0, w1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    ac3_commit(L, nxt);
+    ac3_sync();
+    ac3_fetch(L, t + 2);
+    ac3_load(nxt + L.off_a, nxt + L.off_b, reinterpret_cast<const double *>(nxt + AC3_RAW), 0, r0);
+    __builtin_amdgcn_sched_barrier(0);
+    ac3_convert(r1, L.cb, L.sh, w1);
+    ac3_block<A, LG, false>(w1, w0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int A, int LG>
+__device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][AC3_BUF] */,
+                                         uint32_t frame0, uint32_t nframes, uint32_t n,
+                                         const double *__restrict__ win, uint32_t group) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t total = nframes * 4;
+    const uint32_t cand0 = group * 64;
+    const bool live = cand0 + lane < total;
+    const uint32_t f_lo = cand0 / 4;                       // first frame of this wave (relative)
+    const uint32_t fl = lane >> 2, cand = lane & 3;        // frame within the wave, candidate
+    const uint32_t f_last = nframes - 1;
+    const uint32_t frame = frame0 + (f_lo + fl < nframes ? f_lo + fl : f_last);
+    const CandInfo ci = p.cinfo[(size_t)frame * 4 + cand];
+    const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
+    Ac3Lane L;
+    // candidate = (a + cb * b) >> sh over the frame's rows L (2 fl) and R (2 fl + 1)
+    L.off_a = (2 * fl + (cand == 1 ? 1u : 0u)) * AC3_LD;
+    L.off_b = (2 * fl + 1) * AC3_LD;
+    L.cb = cand == 2 ? 1 : cand == 3 ? -1 : 0;
+    L.sh = wasted + (cand == 2 ? 1u : 0u);
+    L.ntiles = n / AC3_TS;
+    // staging: lane -> (row = it * 8 + lane / 8, 4 samples at column 4 * (lane % 8)); the window
+    // slice (32 f64) is staged by every group of 16 lanes (identical data, same addresses)
+    const uint32_t srow = lane >> 3, scol = (lane & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const uint32_t r = it * 8 + srow;                  // 0..31: frame r / 2, channel r & 1
+        const uint32_t fr = f_lo + r / 2 < nframes ? f_lo + r / 2 : f_last;
+        L.gsrc[it] = p.planar + ((size_t)(frame0 + fr) * 2 + (r & 1)) * p.ldb + scol;
+        L.sdst[it] = r * AC3_LD + scol;
+    }
+    L.wsrc = win + 2 * (lane & 15);
+    L.wdst = AC3_RAW + 4 * (lane & 15);
+    double acc[LG];
 #pragma unroll
     for (int k = 0; k < LG; k++) acc[k] = -0.0;  // f64 `sum()` identity
-#pragma unroll
-    for (int s = 0; s < H; s++) hist[s] = 0.0;
-
-    ac_block<H, A, LG, true, true>(hist, acc, src.a, src.b, src.mode, wasted, win, 0, n);
-    uint32_t base = H;
-    for (; base + H <= n; base += H)
-        ac_block<H, A, LG, false, false>(hist, acc, src.a, src.b, src.mode, wasted, win, base, n);
-    if (base < n)
-        ac_block<H, A, LG, false, true>(hist, acc, src.a, src.b, src.mode, wasted, win, base, n);
-
+    double w0[16], w1[16];
+    Ac3Raw r0, r1;
+    ac3_fetch(L, 0);
+    ac3_commit(L, tile);
+    ac3_sync();
+    ac3_fetch(L, 1);
+    ac3_load(tile + L.off_a, tile + L.off_b, reinterpret_cast<const double *>(tile + AC3_RAW), 0, r0);
+    ac3_tile<A, LG, true>(L, tile, 0, r0, r1, w0, w1, acc);
+#pragma unroll 1
+    for (uint32_t t = 1; t < L.ntiles; t++) ac3_tile<A, LG, false>(L, tile, t, r0, r1, w0, w1, acc);
     if (live) {
-        double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
+        double *out = p.ac + ((size_t)frame * 4 + cand) * AC_LD + A;
 #pragma unroll
         for (int k = 0; k < LG; k++) out[k] = acc[k];
     }
 }
 
-// G = 4 lag groups per candidate (blockIdx.y)
-template <int H>
-__global__ void __launch_bounds__(64) k_autocorr(Params p, uint32_t frame0, uint32_t nframes,
-                                                 uint32_t n, const double *__restrict__ win) {
-    constexpr int LG = H / 4;
-    switch (blockIdx.y) {
-    case 0: ac_body<H, 0 * LG, LG>(p, frame0, nframes, n, win); break;
-    case 1: ac_body<H, 1 * LG, LG>(p, frame0, nframes, n, win); break;
-    case 2: ac_body<H, 2 * LG, LG>(p, frame0, nframes, n, win); break;
-    default: ac_body<H, 3 * LG, LG>(p, frame0, nframes, n, win); break;
+// NL lags split over NS waves; lag ranges are [NL * w / NS, NL * (w + 1) / NS)
+template <int NL, int NS>
+__global__ void __launch_bounds__(64 * NS)
+k_autocorr3(Params p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *__restrict__ win) {
+    __shared__ __attribute__((aligned(16))) int32_t tiles[NS][2 * AC3_BUF];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int32_t *tile = tiles[wave];
+    constexpr int B0 = 0, B1 = NL * 1 / NS, B2 = NL * 2 / NS, B3 = NL * 3 / NS, B4 = NL * 4 / NS;
+    if constexpr (NS == 2) {
+        if (wave == 0) ac3_wave<B0, B1 - B0>(p, tile, frame0, nframes, n, win, blockIdx.x);
+        else ac3_wave<B1, B2 - B1>(p, tile, frame0, nframes, n, win, blockIdx.x);
+    } else {
+        switch (wave) {
+        case 0: ac3_wave<B0, B1 - B0>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        case 1: ac3_wave<B1, B2 - B1>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        case 2: ac3_wave<B2, B3 - B2>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        default: ac3_wave<B3, B4 - B3>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------
-// K3 (tiled): same arithmetic and summation order as ac_body, but the samples reach the lanes
+// K3 (tiled): generic kernel (any candidate set, block length and order); the samples reach the lanes
 // through LDS.  A 256-thread workgroup serves 64 candidates; its 4 waves are the 4 lag groups.
 // Per tile of TS samples:
 //   1. the planar rows those candidates need (<= 72) are staged with coalesced 16-byte loads
@@ -3084,29 +3202,41 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
 // never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
 size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_size) * 4; }
 
+template <int NL>
+void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                      const double *win, hipStream_t st) {
+    // 4 waves per 64 candidates (lags split 4 ways): the f64 stream needs two waves per SIMD to
+    // issue at full rate, and 8192 frames are only 512 candidate groups (measured 0.23 ms
+    // against 0.31 ms with the lags split 2 ways)
+    const uint32_t groups = (nframes * 4 + 63) / 64;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4>), dim3(groups), dim3(256), 0, st, p, frame0,
+                       nframes, n, win);
+}
+// stereo L/R/M/S candidates, <= 24-bit samples, frame length a multiple of 32, order <= 16
+bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+                   hipStream_t st) {
+    if (!p.stereo4 || p.ncand != 4 || p.channels != 2 || p.bps > 24 || n < 32 || n % 32 != 0 ||
+        p.max_lpc_order > 16 || getenv("FLACGPU_NO_AC3"))
+        return false;
+    const uint32_t nl = p.max_lpc_order + 1;
+    if (nl <= 5) launch_autocorr3<5>(p, frame0, nframes, n, win, st);
+    else if (nl <= 9) launch_autocorr3<9>(p, frame0, nframes, n, win, st);
+    else if (nl <= 13) launch_autocorr3<13>(p, frame0, nframes, n, win, st);
+    else launch_autocorr3<17>(p, frame0, nframes, n, win, st);
+    return true;
+}
+
 template <int H>
 void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                      const double *win, hipStream_t st) {
-    uint32_t lanes = nframes * p.ncand;
-    if (getenv("FLACGPU_AC_V1")) {
-        dim3 grid((lanes + 63) / 64, 4);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr<H>), grid, dim3(64), 0, st, p, frame0, nframes,
-                           n, win);
-    } else {
-        if constexpr (H % 8 == 0) {
-            if (getenv("FLACGPU_AC_NW8")) {  // experiment: 8 lag-group waves (slower: 0.43 vs 0.35 ms)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 8>), dim3((lanes + 63) / 64), dim3(512), 0,
-                                   st, p, frame0, nframes, n, win);
-                return;
-            }
-        }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 4>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
-                           frame0, nframes, n, win);
-    }
+    const uint32_t lanes = nframes * p.ncand;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 4>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
+                       frame0, nframes, n, win);
 }
 
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st) {
+    if (try_autocorr3(p, frame0, nframes, n, win, st)) return;
     switch (H) {
     case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
     case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;
