@@ -164,6 +164,9 @@ def main():
             "k_fixed": ("hbm", 8.0 * cand_samples),
             "k_autocorr": ("f64", 2.0 * BLOCK * (MAX_LPC + 1) * n_cand),
             "k_fir": ("hbm", 8.0 * cand_samples),
+            # fused FIXED + LPC + Rice search: every candidate's samples are read once, residuals
+            # never leave registers, 280-byte plan out
+            "k_cand64": ("hbm", 4.0 * cand_samples + 280.0 * n_cand),
             "k_emit": ("hbm", 8.0 * F * BLOCK * CHANNELS),
             "k_pack": ("hbm", 4.0 * F * BLOCK * CHANNELS + compressed_bytes),
             "k_crc": ("hbm", float(compressed_bytes)),
@@ -188,7 +191,7 @@ def main():
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
             if prof and F == FRAMES:
                 t = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                fast = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr2",
+                fast = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr3",
                         "k_deinterleave": "k_deinterleave2"}
                 key = fast.get(dom, dom) if fast.get(dom, dom) in t else dom
                 if key in t:
@@ -198,6 +201,27 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
+        # The integer kernels are bound by VALU instruction issue, not by HBM: one wave64 VALU
+        # instruction holds a SIMD for 4 cycles, so the chip issues at most 1024 SIMDs x clk / 4
+        # wave-instructions per second.  Instruction counts per launch come from the SQ_INSTS_VALU
+        # pass of tools/collect_profiles.sh (deterministic for a given input).
+        try:
+            vprof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_valu.json"))
+            if vprof and F == FRAMES:
+                vt = json.load(open(os.path.join(ROOT, "profiles", vprof[-1])))
+                key = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr3",
+                       "k_deinterleave": "k_deinterleave2"}.get(dom, dom)
+                if key in vt and vt[key].get("SQ_INSTS_VALU"):
+                    insts = vt[key]["SQ_INSTS_VALU"]
+                    peak_issue = 1024 * 2.4e9 / 4
+                    roofline["valu_issue"] = {
+                        "wave_insts_per_launch": insts, "source": vprof[-1],
+                        "achieved_Ginst/s": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
+                        "peak_Ginst/s": round(peak_issue / 1e9, 1),
+                        "frac": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / peak_issue, 4),
+                        "valu_active_per_wave_cycle": vt[key].get("valu_active_per_wave_cycle")}
+        except Exception:
+            pass
 
         # ---- CPU baseline: the oracle (C restatement of the reference, NOT the Rust binary),
         # timed on this box's host cores over the same workload

@@ -3,6 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats            -> gpurun_out/<tag>/stats
 #   2. rocprofv3 --pmc FETCH_SIZE                  -> gpurun_out/<tag>/fetch   (separate pass)
 #   3. rocprofv3 --pmc WRITE_SIZE                  -> gpurun_out/<tag>/write   (separate pass)
+#   4. rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES -> .../valu
 # (counter passes never combine with trace domains other than kernel-trace; see MI355X guide)
 set -e
 TAG=${1:-r01}
@@ -13,5 +14,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/valu.log 2>&1 || true
 cd $ROOT && python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 ls -R $OUT | head -30

@@ -37,6 +37,19 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb),
               "raw_FETCH_SIZE_KiB": fetch.get(k), "raw_WRITE_SIZE_KiB": write.get(k)}
 json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+# VALU issue counters (per launch, summed over the chip).  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES
+# count quad-cycles (MI355X_MICROARCH.md), SQ_INSTS_VALU counts wave-instructions.
+valu = {}
+for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES"):
+    for k, v in per_kernel("valu", c).items():
+        valu.setdefault(k, {})[c] = v
+for k, v in valu.items():
+    if v.get("SQ_WAVE_CYCLES"):
+        v["valu_active_per_wave_cycle"] = round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"], 4)
+    if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
+        v["valu_insts_per_wave"] = round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1)
+if valu:
+    json.dump(valu, open(f"profiles/{tag}_valu.json", "w"), indent=1)
 stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
