@@ -1877,30 +1877,84 @@ __device__ __forceinline__ uint32_t sread(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// Residual sources of wave_rice.  resid(e) is called with e = 0..63 ascending after reset().
+// StoredSrc: residuals held in a register array (the LPC residual, computed in place over the
+// samples); they are folded in place by the first pass.
+struct StoredSrc {
+    static constexpr bool STORED = true;
+    int32_t (&a)[64];
+    __device__ __forceinline__ void reset() {}
+    __device__ __forceinline__ int32_t resid(int e) { return a[e]; }
+};
+// FixedSrc<K>: residual of fixed order K generated on the fly from the samples (encode.rs:
+// 3039-3060); nothing is stored, the second pass of the search simply regenerates it (K
+// subtractions per sample) -- this keeps the kernel at 64 instead of 128 array registers.
+template <int K>
+struct FixedSrc {
+    static constexpr bool STORED = false;
+    int32_t (&x)[64];
+    int32_t (&h)[4];  // the 4 samples before x[0]
+    int32_t q0, q1, q2, q3;
+    __device__ __forceinline__ void reset() {
+        // make the samples opaque: otherwise the compiler shares this pass's differences with
+        // the previous pass (and with the order statistics), i.e. keeps 64..256 of them live
+#pragma unroll
+        for (int e = 0; e < 64; e++) asm volatile("" : "+v"(x[e]));
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(h[k]));
+        q0 = h[3];
+        q1 = h[3] - h[2];
+        q2 = q1 - (h[2] - h[1]);
+        q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
+    }
+    __device__ __forceinline__ int32_t resid(int e) {
+        const int32_t d1 = x[e] - q0, d2 = d1 - q1, d3 = d2 - q2, d4 = d3 - q3;
+        q0 = x[e]; q1 = d1; q2 = d2; q3 = d3;
+        return K == 0 ? x[e] : K == 1 ? d1 : K == 2 ? d2 : K == 3 ? d3 : d4;
+    }
+};
+
 // Rice search of one wave's residual (encode.rs:3862-3947), lane l = samples [64 l, 64 l + 64).
-// `res` is consumed: warm-up entries (lane 0, e < order <= MAXORD) are zeroed and every value
-// is folded to t = r ^ (r >> 31) = zigzag(r) >> 1, so that
+// Warm-up entries (lane 0, e < order <= MAXORD) count as zero and every value is folded to
+// t = r ^ (r >> 31) = zigzag(r) >> 1, so that
 //   sum |r| = sum t + #negative,  zigzag(r) >> k = t >> (k - 1) for k >= 1,
 //   sum zigzag(r) = 2 sum t + #negative.
 // Level totals come from one DPP scan of the node estimates plus ballots; nothing touches LDS.
-template <int MAXORD>
-__device__ __forceinline__ WaveRice wave_rice(int32_t (&res)[64], uint32_t order, const Params &p) {
+// folded value of sample e in the second and later passes
+template <int MAXORD, class Src>
+__device__ __forceinline__ uint32_t rice_folded(Src &src, int e, uint32_t first) {
+    if constexpr (Src::STORED) {
+        return (uint32_t)src.a[e];
+    } else {
+        int32_t r = src.resid(e);
+        if (e < MAXORD) r = (uint32_t)e >= first ? r : 0;
+        return (uint32_t)(r ^ (r >> 31));
+    }
+}
+template <int MAXORD, class Src>
+__device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Params &p) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = rice_levels(FN, p);
     const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
     const uint32_t first = lane == 0 ? order : 0u;
-#pragma unroll
-    for (int e = 0; e < MAXORD; e++) res[e] = (uint32_t)e >= first ? res[e] : 0;
     uint64_t sum_t = 0;
     uint32_t neg = 0;
+    src.reset();
 #pragma unroll
     for (int e = 0; e < 64; e += 2) {
-        const int32_t s0 = res[e] >> 31, s1 = res[e + 1] >> 31;
-        res[e] ^= s0;
-        res[e + 1] ^= s1;
+        int32_t r0 = src.resid(e), r1 = src.resid(e + 1);
+        if (e < MAXORD) r0 = (uint32_t)e >= first ? r0 : 0;
+        if (e + 1 < MAXORD) r1 = (uint32_t)(e + 1) >= first ? r1 : 0;
+        const int32_t s0 = r0 >> 31, s1 = r1 >> 31;
+        const uint32_t t0 = (uint32_t)(r0 ^ s0), t1 = (uint32_t)(r1 ^ s1);
+        if constexpr (Src::STORED) {
+            src.a[e] = (int32_t)t0;
+            src.a[e + 1] = (int32_t)t1;
+        }
         neg -= (uint32_t)s0;
         neg -= (uint32_t)s1;
-        sum_t += (uint32_t)res[e] + (uint32_t)res[e + 1];  // each < 2^31
+        sum_t += t0 + t1;  // each < 2^31
+        if ((e & 7) == 6) __builtin_amdgcn_sched_barrier(0);
     }
     const uint64_t mysum = sum_t + neg;  // sum |r| of this lane's 64 samples, < 2^37
     // inclusive prefix of the leaf sums in two limbs
@@ -1987,8 +2041,12 @@ __device__ __forceinline__ WaveRice wave_rice(int32_t (&res)[64], uint32_t order
         const uint32_t k = (mrec >> 18) & 0xFF;
         const uint32_t sh = (k == 0 || k == 0xFF) ? 0u : k - 1u;
         uint32_t q = 0;
+        src.reset();
 #pragma unroll
-        for (int e = 0; e < 64; e++) q += (uint32_t)res[e] >> sh;
+        for (int e = 0; e < 64; e++) {
+            q += rice_folded<MAXORD>(src, e, first) >> sh;
+            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
         mine += k == 0xFF ? 0u : k == 0 ? 2u * (uint32_t)sum_t + neg : q;
     } else {
         if (lane == 0) {
@@ -1997,8 +2055,9 @@ __device__ __forceinline__ WaveRice wave_rice(int32_t (&res)[64], uint32_t order
             mine += 4u + 5u + 31u * (FN - order);
         }
         // t >= 2^30  <=>  r outside [-2^30, 2^30): write_signed_counted(31) fails (:3857)
+        src.reset();
 #pragma unroll
-        for (int e = 0; e < 64; e++) wide |= (uint32_t)res[e] >= (1u << 30);
+        for (int e = 0; e < 64; e++) wide |= rice_folded<MAXORD>(src, e, first) >= (1u << 30);
     }
     w.bits = 6u + wave_total_u32(mine);  // method (2) + partition order (4), :3949, :3902
     w.ok = !__any(wide);
@@ -2010,12 +2069,11 @@ __device__ __forceinline__ WaveRice wave_rice(int32_t (&res)[64], uint32_t order
 // Returns the sign-bit OR of every i32 subtraction overflow outside the warm-up
 // (ResidualOverflow, encode.rs:3190-3197).
 template <int T>
-__device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[16],
-                                          const int32_t *__restrict__ qlp, uint32_t order,
-                                          uint32_t shift) {
-    int32_t c[T];
+__device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[16], uint32_t lpw,
+                                          uint32_t order, uint32_t shift) {
+    int32_t c[T];  // wave-uniform (SGPRs): coefficient j was loaded by lane 2 + j
 #pragma unroll
-    for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? __builtin_amdgcn_readfirstlane(qlp[j]) : 0;
+    for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? (int32_t)sread(lpw, 2 + j) : 0;
     // bit e set: sample e of this lane is warm-up (lane 0 only)
     const uint32_t warm = (threadIdx.x & 63) == 0 ? ((1u << order) - 1u) : 0u;
     uint32_t ovf = 0;
@@ -2034,27 +2092,15 @@ __device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[
         if (e < 16) o &= ~(warm << (31 - e));
         ovf |= o;
         x[e] = d;
+        if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     return ovf >> 31;
-}
-
-// residual of fixed order K from the lane's samples and the 4 before them (encode.rs:3039-3060)
-template <int K>
-__device__ __forceinline__ void fixed64(const int32_t (&x)[64], const int32_t (&h)[4], int32_t (&res)[64]) {
-    int32_t q0 = h[3], q1 = h[3] - h[2], q2 = (h[3] - h[2]) - (h[2] - h[1]);
-    int32_t q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
-#pragma unroll
-    for (int e = 0; e < 64; e++) {
-        const int32_t d1 = x[e] - q0, d2 = d1 - q1, d3 = d2 - q2, d4 = d3 - q3;
-        res[e] = K == 0 ? x[e] : K == 1 ? d1 : K == 2 ? d2 : K == 3 ? d3 : d4;
-        q0 = x[e]; q1 = d1; q2 = d2; q3 = d3;
-    }
 }
 
 __device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uint32_t wasted,
                                                 uint32_t bps, uint32_t order, uint32_t precision,
                                                 uint32_t shift, uint32_t source, uint32_t bits,
-                                                const WaveRice *w, const int32_t *qlp) {
+                                                const WaveRice *w, uint32_t coeff /* of `lane` */) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *d = reinterpret_cast<uint32_t *>(dst);
     if (lane == 0) {
@@ -2068,7 +2114,7 @@ __device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uin
         d[4] = w ? (w->bp >= 0 ? FN >> w->bp : FN) : 0u;     // part_len
         d[5] = bits;
     }
-    if (lane < 32) d[6 + lane] = (qlp && lane < order) ? (uint32_t)qlp[lane] : 0u;  // coeffs
+    if (lane < 32) d[6 + lane] = lane < order ? coeff : 0u;  // coeffs
     uint8_t *b = reinterpret_cast<uint8_t *>(dst);
     const bool live = w && lane < w->count;
     b[24 + 128 + lane] = live ? w->price : 0;        // rice[lane]
@@ -2082,16 +2128,17 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     if (local >= p.fcount * p.ncand) return;
     const uint32_t frame = p.f0 + local / p.ncand, cand = local % p.ncand;
     const size_t cidx = (size_t)frame * p.ncand + cand;
-    const CandInfo ci = p.cinfo[cidx];
-    if (!ci.active) return;
+    // Everything the wave needs from memory is requested up front, so that one round trip is
+    // exposed instead of four: candidate info, the LPC parameters (one coalesced dword per lane:
+    // [0] status, [1] order | precision << 8 | shift << 16, [2..33] coefficients; handed out
+    // with v_readlane later) and the samples.
+    static_assert(sizeof(CandInfo) == 4 && sizeof(LpcParams) == 136, "layout");
+    const uint32_t ci_raw = *reinterpret_cast<const uint32_t *>(p.cinfo + cidx);
+    const uint32_t *lpw_p = reinterpret_cast<const uint32_t *>(p.lpc + cidx);
+    const bool want_lpc = p.max_lpc_order > 0;
+    const uint32_t lpw = (want_lpc && lane < 34) ? lpw_p[lane] : 1u;       // status 1 = no LPC
+    const uint32_t qv = (want_lpc && lane < 32) ? lpw_p[2 + lane] : 0u;     // coefficient `lane`
     const CandSrc src = cand_src(p, frame, cand);
-    SubPlan *out = p.cand_plan + cidx;
-    if (ci.is_const) {  // all zero -> CONSTANT(0) at the candidate's bps (encode.rs:2883-2887)
-        store_plan_wave(out, FLACGPU_SUB_CONSTANT, 0, src.bps, 0, 0, 0, src.source, 8u + src.bps, nullptr, nullptr);
-        return;
-    }
-    const uint32_t wasted = __builtin_amdgcn_readfirstlane((uint32_t)ci.wasted);
-    const uint32_t bps_eff = __builtin_amdgcn_readfirstlane((uint32_t)ci.bps);
     int32_t x[64];
     {
         const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 16 * lane;
@@ -2100,24 +2147,38 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int4 a = pa[q];
-                x[4 * q] = a.x >> wasted; x[4 * q + 1] = a.y >> wasted;
-                x[4 * q + 2] = a.z >> wasted; x[4 * q + 3] = a.w >> wasted;
+                x[4 * q] = a.x; x[4 * q + 1] = a.y; x[4 * q + 2] = a.z; x[4 * q + 3] = a.w;
             }
-        } else if (src.mode == 1) {
+        } else if (src.mode == 1) {  // mid = (l + r) >> 1: the shift joins the wasted-bits shift
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int4 a = pa[q], b = pb[q];
-                x[4 * q] = combine(1, a.x, b.x) >> wasted; x[4 * q + 1] = combine(1, a.y, b.y) >> wasted;
-                x[4 * q + 2] = combine(1, a.z, b.z) >> wasted; x[4 * q + 3] = combine(1, a.w, b.w) >> wasted;
+                x[4 * q] = (int32_t)((uint32_t)a.x + (uint32_t)b.x); x[4 * q + 1] = (int32_t)((uint32_t)a.y + (uint32_t)b.y);
+                x[4 * q + 2] = (int32_t)((uint32_t)a.z + (uint32_t)b.z); x[4 * q + 3] = (int32_t)((uint32_t)a.w + (uint32_t)b.w);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int4 a = pa[q], b = pb[q];
-                x[4 * q] = combine(2, a.x, b.x) >> wasted; x[4 * q + 1] = combine(2, a.y, b.y) >> wasted;
-                x[4 * q + 2] = combine(2, a.z, b.z) >> wasted; x[4 * q + 3] = combine(2, a.w, b.w) >> wasted;
+                x[4 * q] = combine(2, a.x, b.x); x[4 * q + 1] = combine(2, a.y, b.y);
+                x[4 * q + 2] = combine(2, a.z, b.z); x[4 * q + 3] = combine(2, a.w, b.w);
             }
         }
+    }
+    CandInfo ci;
+    memcpy(&ci, &ci_raw, 4);
+    if (!ci.active) return;
+    SubPlan *out = p.cand_plan + cidx;
+    if (ci.is_const) {  // all zero -> CONSTANT(0) at the candidate's bps (encode.rs:2883-2887)
+        store_plan_wave(out, FLACGPU_SUB_CONSTANT, 0, src.bps, 0, 0, 0, src.source, 8u + src.bps, nullptr, 0);
+        return;
+    }
+    const uint32_t wasted = __builtin_amdgcn_readfirstlane((uint32_t)ci.wasted);
+    const uint32_t bps_eff = __builtin_amdgcn_readfirstlane((uint32_t)ci.bps);
+    {
+        const uint32_t sh = wasted + (src.mode == 1 ? 1u : 0u);
+#pragma unroll
+        for (int e = 0; e < 64; e++) x[e] >>= sh;
     }
     // the previous lane's last 4 samples (zeros before the block start)
     int32_t h[4];
@@ -2150,6 +2211,7 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
             if ((e & 7) == 7) {
                 sm[0] += a0; sm[1] += a1; sm[2] += a2; sm[3] += a3; sm[4] += a4;
                 a0 = a1 = a2 = a3 = a4 = 0;
+                __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 64 chains
             }
         }
         if (lane == 0) { sm[0] -= c0; sm[1] -= c1; sm[2] -= c2; sm[3] -= c3; sm[4] -= c4; }
@@ -2160,43 +2222,42 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
 #pragma unroll
     for (uint32_t k = 1; k <= 4; k++)
         if (sm[k] < sm[forder]) forder = k;  // min_by_key: first minimum wins
-    int32_t res[64];
+    WaveRice fw;
     switch (forder) {
-    case 0: fixed64<0>(x, h, res); break;
-    case 1: fixed64<1>(x, h, res); break;
-    case 2: fixed64<2>(x, h, res); break;
-    case 3: fixed64<3>(x, h, res); break;
-    default: fixed64<4>(x, h, res); break;
+    case 0: fw = wave_rice<4>(FixedSrc<0>{x, h}, 0, p); break;
+    case 1: fw = wave_rice<4>(FixedSrc<1>{x, h}, 1, p); break;
+    case 2: fw = wave_rice<4>(FixedSrc<2>{x, h}, 2, p); break;
+    case 3: fw = wave_rice<4>(FixedSrc<3>{x, h}, 3, p); break;
+    default: fw = wave_rice<4>(FixedSrc<4>{x, h}, 4, p); break;
     }
-    const WaveRice fw = wave_rice<4>(res, forder, p);
     const uint32_t fixed_bits = 8u + wasted + forder * bps_eff + fw.bits;
     const bool fixed_ok = fw.ok;
     // ---- LPC (encode.rs:3174-3203 + the same residual coding)
     bool lpc_ok = false;
     uint32_t lpc_bits = 0;
     WaveRice lw = fw;
-    const LpcParams *lp = p.lpc + cidx;
+    const uint32_t lstatus = sread(lpw, 0), lmeta = sread(lpw, 1);
+    const uint32_t lprec = (lmeta >> 8) & 0xFF, lshift = (lmeta >> 16) & 0xFF;
     uint32_t lorder = 0;
-    if (p.max_lpc_order > 0 && lp->status == 0) {
-        lorder = __builtin_amdgcn_readfirstlane((uint32_t)lp->order);
-        const uint32_t shift = __builtin_amdgcn_readfirstlane((uint32_t)lp->shift);
+    if (lstatus == 0) {
+        lorder = lmeta & 0xFF;
         int32_t hp[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) hp[k] = lane_prev(x[48 + k]);
         uint32_t ovf;
         switch ((lorder + 3) >> 2) {
-        case 1: ovf = fir64<4>(x, hp, lp->qlp, lorder, shift); break;
-        case 2: ovf = fir64<8>(x, hp, lp->qlp, lorder, shift); break;
-        case 3: ovf = fir64<12>(x, hp, lp->qlp, lorder, shift); break;
-        default: ovf = fir64<16>(x, hp, lp->qlp, lorder, shift); break;
+        case 1: ovf = fir64<4>(x, hp, lpw, lorder, lshift); break;
+        case 2: ovf = fir64<8>(x, hp, lpw, lorder, lshift); break;
+        case 3: ovf = fir64<12>(x, hp, lpw, lorder, lshift); break;
+        default: ovf = fir64<16>(x, hp, lpw, lorder, lshift); break;
         }
         if (__any(ovf)) {
             if (lane == 0) atomicAdd(&p.stats[0], 1u);
         } else {
-            lw = wave_rice<16>(x, lorder, p);
+            lw = wave_rice<16>(StoredSrc{x}, lorder, p);
             lpc_ok = lw.ok;
             if (!lpc_ok && lane == 0) atomicAdd(&p.stats[0], 1u);
-            lpc_bits = 8u + wasted + lorder * bps_eff + 4u + 5u + lorder * lp->precision + lw.bits;
+            lpc_bits = 8u + wasted + lorder * bps_eff + 4u + 5u + lorder * lprec + lw.bits;
         }
     }
     // (Ok,Ok) -> min_by_key(written) with FIXED first; (Err,Ok) -> LPC; (Ok,Err) -> FIXED;
@@ -2206,13 +2267,13 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < FN * bps_eff);
     if (verbatim)
         store_plan_wave(out, FLACGPU_SUB_VERBATIM, wasted, bps_eff, 0, 0, 0, src.source,
-                        8u + wasted + FN * bps_eff, nullptr, nullptr);
+                        8u + wasted + FN * bps_eff, nullptr, 0);
     else if (use_lpc)
-        store_plan_wave(out, FLACGPU_SUB_LPC, wasted, bps_eff, lorder, lp->precision, lp->shift,
-                        src.source, lpc_bits, &lw, lp->qlp);
+        store_plan_wave(out, FLACGPU_SUB_LPC, wasted, bps_eff, lorder, lprec, lshift, src.source, lpc_bits,
+                        &lw, qv);
     else
         store_plan_wave(out, FLACGPU_SUB_FIXED, wasted, bps_eff, forder, 0, 0, src.source, fixed_bits,
-                        &fw, nullptr);
+                        &fw, 0);
 }
 
 // ---------------------------------------------------------------------------------
