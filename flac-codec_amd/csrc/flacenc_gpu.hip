@@ -2522,39 +2522,25 @@ __device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, 
 // MODE 0: any block length, residual rows read from HBM (written by k_emit)
 // MODE 1: 4096-sample blocks, residual rows read from HBM into registers
 // MODE 2: 4096-sample blocks, residuals RECOMPUTED from the PCM in registers (k_emit not needed)
+// One subframe's bits written into the MSB-first LDS bit string `sb` (zeroed by the caller, which
+// has NOT synchronised yet) starting at bit `base`; `with_header` also writes the frame header at
+// bit 0.  xs: WG x 20 ints of LDS scratch (MODE 2).  Ends WITHOUT a barrier.
 template <int MODE, int PREV>
-__global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
+__device__ __forceinline__ void pack_subframe(const Params &p, const PackParams &q, uint32_t frame,
+                                              uint32_t ch, uint32_t n, uint32_t *sb, uint32_t base,
+                                              bool with_header, int32_t *xs, const HeaderCodes &hc,
+                                              uint64_t fn) {
     constexpr bool FAST = MODE != 0;
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ uint32_t wave_tot[4];
     __shared__ uint8_t hdr[16];
-    uint32_t frame, ch;
-    map_block(blockIdx.x, p.channels, p.fcount, frame, ch);
-    frame += p.f0;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = frame_len(p, frame);
     const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
     const uint32_t type = sp->type, order = sp->order, wasted = sp->wasted, bps = sp->bps;
-    const uint32_t sub_bits = sp->bits;
-
-    // position of this subframe inside the frame
-    const uint64_t fn = q.first_frame_number + frame;
-    const HeaderCodes hc = header_codes(n, q.sample_rate, fn);
-    const uint32_t hbytes = header_bytes(hc);
-    uint32_t start_bit = hbytes * 8;
-    for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
-    const uint32_t prefix_bits = ch == 0 ? hbytes * 8 : 0;  // subframe 0 also carries the header
-    const uint32_t total_bits = prefix_bits + sub_bits;
-    const uint32_t nwords = (total_bits + 31) / 32 + 1;
-
-    uint32_t *sb = reinterpret_cast<uint32_t *>(lds);  // the subframe's bit string
-    for (uint32_t i = tid; i < nwords; i += WG) sb[i] = 0;
     // residual row: every lane reads its own contiguous run straight from HBM/L2 (twice:
     // lengths, then codes; the second pass hits L1/L2)
     const int32_t *__restrict__ r = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
     int32_t v16[16];  // FAST (n == 4096): this lane's residuals [16 tid, 16 tid + 16) in registers
     // MODE 2 keeps the wasted-bit-shifted samples of the source candidate in LDS (20-dword rows)
-    int32_t *xs = lds + pack_sb_words(FN);
     __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
     auto rd = [&](uint32_t i) -> int32_t {
         if constexpr (MODE == 2) return xs[(i >> 4) * 20 + (i & 15)];
@@ -2633,9 +2619,8 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
         }
     }
 
-    const uint32_t base = prefix_bits;  // bit where the subframe starts inside sb
     if (tid == 0) {
-        if (ch == 0) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
+        if (with_header) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
             const flacgpu_frame_plan fp = p.frame_plan[frame];
             uint32_t k = 0;
             hdr[k++] = 0xFF;
@@ -2807,6 +2792,31 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
             else { lds_put(sb, pos, esc_code, hb); lds_put(sb, pos + hb, eb, 5); }
         }
     }
+}
+
+template <int MODE, int PREV>
+__global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    uint32_t frame, ch;
+    map_block(blockIdx.x, p.channels, p.fcount, frame, ch);
+    frame += p.f0;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = frame_len(p, frame);
+    const uint32_t sub_bits = p.out_plan[(size_t)frame * p.channels + ch].bits;
+
+    // position of this subframe inside the frame
+    const uint64_t fn = q.first_frame_number + frame;
+    const HeaderCodes hc = header_codes(n, q.sample_rate, fn);
+    const uint32_t hbytes = header_bytes(hc);
+    uint32_t start_bit = hbytes * 8;
+    for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
+    const uint32_t prefix_bits = ch == 0 ? hbytes * 8 : 0;  // subframe 0 also carries the header
+    const uint32_t total_bits = prefix_bits + sub_bits;
+    const uint32_t nwords = (total_bits + 31) / 32 + 1;
+
+    uint32_t *sb = reinterpret_cast<uint32_t *>(lds);  // the subframe's bit string
+    for (uint32_t i = tid; i < nwords; i += WG) sb[i] = 0;
+    pack_subframe<MODE, PREV>(p, q, frame, ch, n, sb, prefix_bits, ch == 0, lds + pack_sb_words(FN), hc, fn);
     __syncthreads();
     // copy out: absolute bit position of sb[0] in the output stream
     const uint64_t abs_bit = q.frame_off[frame] * 8ull + (ch == 0 ? 0u : start_bit);
@@ -2857,6 +2867,124 @@ struct CrcWeights {
 };
 __constant__ CrcWeights kCrcW = CrcWeights();
 
+// W17[k] = x^(544 k) mod P: weight of a 68-byte slice that is followed by k more slices
+struct CrcWeights17 {
+    uint16_t w[WG + 1];
+    constexpr CrcWeights17() : w() {
+        uint32_t x32 = 0x100;                       // x^8
+        x32 = gf_mulmod_c(x32, x32);                // x^16
+        x32 = gf_mulmod_c(x32, x32);                // x^32
+        uint32_t x544 = 1;
+        for (int i = 0; i < 17; i++) x544 = gf_mulmod_c(x544, x32);
+        uint32_t v = 1;
+        for (int k = 0; k <= WG; k++) {
+            w[k] = (uint16_t)v;
+            v = gf_mulmod_c(v, x544);
+        }
+    }
+};
+__constant__ CrcWeights17 kCrcW17 = CrcWeights17();
+
+// words of LDS a whole frame of 4096-sample subframes may need (VERBATIM everywhere + header +
+// CRC-16 + one guard word for the funnel shifts); multiple of 4 words
+__host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps) {
+    return (((16u + 2u) * 8u + channels * (FN * (bps + 1u) + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
+}
+
+// ---------------------------------------------------------------------------------
+// K9+K10 fused for 4096-sample frames: ONE workgroup assembles a whole frame in LDS -- header,
+// every subframe at its bit offset (the same pack_subframe as k_pack), byte-alignment padding --
+// computes the CRC-16 from LDS (256 slices of 17 words: conflict-free strides, GF(2)-linear
+// combination as in k_crc), appends it and writes the finished bytes to HBM once, with plain
+// stores (interior dwords) and byte stores (the two ends): no zero-fill of the output, no
+// atomics, and the frame is never read back from HBM.
+// ---------------------------------------------------------------------------------
+template <int PREV>
+__global__ void __launch_bounds__(WG) k_frame(Params p, PackParams q, uint32_t fb_words) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ uint16_t T[4][256];  // slicing-by-4 tables
+    __shared__ uint32_t part[4];
+    const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
+    uint32_t *fb = reinterpret_cast<uint32_t *>(lds);
+    int32_t *xs = lds + fb_words;
+    const uint64_t fn = q.first_frame_number + frame;
+    const HeaderCodes hc = header_codes(FN, q.sample_rate, fn);
+    const uint64_t begin = q.frame_off[frame];
+    const uint32_t flen = (uint32_t)(q.frame_off[frame + 1] - begin);  // bytes, CRC-16 included
+    const uint32_t nwords = (flen + 3) / 4 + 1;
+    for (uint32_t i = tid; i < nwords; i += WG) fb[i] = 0;
+    {
+        uint32_t c = tid << 8;
+        for (int k = 0; k < 4; k++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
+            for (int b = 0; b < 8; b++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
+            T[k][tid] = (uint16_t)c;
+        }
+    }
+    uint32_t start_bit = header_bytes(hc) * 8;
+    for (uint32_t ch = 0; ch < p.channels; ch++) {
+        pack_subframe<2, PREV>(p, q, frame, ch, FN, fb, start_bit, ch == 0, xs, hc, fn);
+        start_bit += p.out_plan[(size_t)frame * p.channels + ch].bits;
+        __syncthreads();
+    }
+    // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4))
+    const uint32_t len = flen - 2;
+    constexpr uint32_t CH = WG * 68;                 // bytes per pass
+    const uint32_t my_weight = kCrcW17.w[WG - 1 - tid];
+    const uint32_t xchunk = kCrcW17.w[WG];
+    uint32_t running = 0;
+    for (uint32_t pos = 0; pos < len;) {
+        // the first pass takes the odd-sized head, right-aligned in the 256 x 68-byte window
+        // (left-padded with zero bytes, which leave a zero CRC state unchanged)
+        const uint32_t clen = (pos == 0 && (len % CH)) ? len % CH : CH;
+        const int32_t f0 = (int32_t)pos - (int32_t)(CH - clen) + (int32_t)(68 * tid);  // first frame byte of my slice
+        const int32_t w0 = f0 >> 2;                  // floor: f0 may be negative
+        const uint32_t sh = ((uint32_t)f0 & 3u) * 8u;
+        uint32_t crc = 0;
+        uint32_t cur = w0 >= 0 ? fb[w0] : 0u;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            const int32_t wn = w0 + k + 1;
+            const uint32_t nxt = wn >= 0 ? fb[wn] : 0u;
+            const uint32_t m = sh ? (cur << sh) | (nxt >> (32 - sh)) : cur;
+            crc = T[3][((crc >> 8) ^ (m >> 24)) & 0xFF] ^ T[2][(crc ^ (m >> 16)) & 0xFF] ^
+                  T[1][(m >> 8) & 0xFF] ^ T[0][m & 0xFF];
+            cur = nxt;
+        }
+        uint32_t c = gf_mulmod(crc, my_weight);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c ^= __shfl_xor(c, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) part[tid >> 6] = c;
+        __syncthreads();
+        running = gf_mulmod(running, xchunk) ^ part[0] ^ part[1] ^ part[2] ^ part[3];
+        pos += clen;
+    }
+    if (tid == 0) {  // the two CRC bytes follow byte len - 1 (still zero there)
+        atomicOr(&fb[len >> 2], ((running >> 8) & 0xFF) << (24 - 8 * (len & 3)));
+        atomicOr(&fb[(len + 1) >> 2], (running & 0xFF) << (24 - 8 * ((len + 1) & 3)));
+    }
+    __syncthreads();
+    // ---- copy out: output dword j covers frame bytes [4 j - r, 4 j - r + 4)
+    uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
+    const uint32_t r = (uint32_t)(begin & 3);
+    uint32_t *og = reinterpret_cast<uint32_t *>(ob + (begin - r));
+    const uint32_t nout = (r + flen + 3) / 4;
+    for (uint32_t j = tid; j < nout; j += WG) {
+        const uint32_t hi = (r && j == 0) ? 0u : fb[j - (r ? 1u : 0u)];
+        const uint32_t m = r ? (hi << (8 * (4 - r))) | (fb[j] >> (8 * r)) : hi;  // MSB-first window
+        const int32_t fbyte = (int32_t)(4 * j) - (int32_t)r;                     // frame byte of the low address
+        if (fbyte >= 0 && fbyte + 4 <= (int32_t)flen) {
+            og[j] = __builtin_bswap32(m);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int32_t fbk = fbyte + e;
+                if (fbk >= 0 && fbk < (int32_t)flen) ob[begin + fbk] = (uint8_t)(m >> (24 - 8 * e));
+            }
+        }
+    }
+}
+
 // VERIFY = false: store the CRC-16 behind the frame; true: compare with the stored one and
 // count mismatching frames in verify_counts[1]
 template <bool VERIFY>
@@ -2864,7 +2992,7 @@ __global__ void __launch_bounds__(WG) k_crc(Params p, PackParams q, uint32_t *ve
     __shared__ uint16_t T[4][256];                 // slicing-by-4 tables
     __shared__ uint32_t buf[CRC_CHUNK / 4 + WG];   // one pad dword per 64-byte slice
     __shared__ uint32_t part[4];
-    const uint32_t frame = blockIdx.x, tid = threadIdx.x;
+    const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
     {
         uint32_t c = tid << 8;
         for (int k = 0; k < 4; k++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
@@ -3657,20 +3785,32 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
     if (c->timing) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
-    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
+    // frames of exactly 4096 samples are assembled whole in LDS by k_frame (residuals recomputed
+    // from the PCM, CRC-16 from LDS, one write of the finished bytes); any other frame goes
+    // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
+    // atomic OR at shared words) -> k_crc
+    const bool fast16 = p.block_size == FN && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
+                        !getenv("FLACGPU_NO_FAST");
+    const uint32_t n_fast = fast16 ? (p.last_len == p.block_size ? p.n_frames : p.n_frames - 1) : 0;
+    const uint32_t fbw = frame_fb_words(p.channels, c->bps);
+    const size_t lds_frame = ((size_t)fbw + WG * 20) * sizeof(int32_t);
+    const bool fused = n_fast && lds_frame <= 64 * 1024 && !getenv("FLACGPU_NO_FUSED_PACK");
+    Params pf = p, pg = p;
+    pf.f0 = 0;
+    pf.fcount = n_fast;
+    pg.f0 = n_fast;
+    pg.fcount = p.n_frames - n_fast;
+    const bool need_zero = !fused || pg.fcount;
+    if (need_zero) hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
     if (c->timing) (void)hipEventRecord(ev[1], st);
-    {   // frames of exactly 4096 samples take the register fast path, which recomputes the
-        // residuals from the PCM (k_emit is only run for the frames that need its rows)
-        const bool fast16 = p.block_size == FN && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
-                            !getenv("FLACGPU_NO_FAST");
-        const uint32_t n_fast = fast16 ? (p.last_len == p.block_size ? p.n_frames : p.n_frames - 1) : 0;
-        Params pf = p, pg = p;
-        pf.f0 = 0;
-        pf.fcount = n_fast;
-        pg.f0 = n_fast;
-        pg.fcount = p.n_frames - n_fast;
+    {
         const size_t lds = pack_lds_bytes(p.block_size);
-        if (pf.fcount) {
+        if (pf.fcount && fused) {
+            if (p.max_lpc_order <= 16)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<1>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<2>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
+        } else if (pf.fcount) {
             const size_t lds2 = lds + WG * 20 * sizeof(int32_t);
             if (p.max_lpc_order <= 16)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<2, 1>), dim3(pf.fcount * p.channels), dim3(WG), lds2, st, pf, q);
@@ -3686,7 +3826,12 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
         }
     }
     if (c->timing) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_crc<false>, dim3(p.n_frames), dim3(WG), 0, st, p, q, (uint32_t *)nullptr);
+    {   // CRC-16 of the frames that did not take the fused kernel
+        Params pc = p;
+        pc.f0 = fused ? n_fast : 0;
+        pc.fcount = p.n_frames - pc.f0;
+        if (pc.fcount) hipLaunchKernelGGL(k_crc<false>, dim3(pc.fcount), dim3(WG), 0, st, pc, q, (uint32_t *)nullptr);
+    }
     if (c->timing) (void)hipEventRecord(ev[3], st);
     HIP_TRY(hipGetLastError());
     c->packed_valid = true;
