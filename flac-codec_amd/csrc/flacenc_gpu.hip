@@ -2068,12 +2068,17 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
 // hp[16] = the 16 samples before them (zeros for lane 0); coefficients are wave-uniform.
 // Returns the sign-bit OR of every i32 subtraction overflow outside the warm-up
 // (ResidualOverflow, encode.rs:3190-3197).
-template <int T>
+struct KeepResidual {  // fir64 consumer: just store the residual
+    __device__ __forceinline__ int32_t operator()(int, int32_t d) { return d; }
+};
+// f(e, residual) -> value stored in x[e]: lets a caller consume each residual where it is
+// produced (k_frame64 sums the code lengths there)
+template <int T, int CBASE = 2, class F = KeepResidual>
 __device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[16], uint32_t lpw,
-                                          uint32_t order, uint32_t shift) {
-    int32_t c[T];  // wave-uniform (SGPRs): coefficient j was loaded by lane 2 + j
+                                          uint32_t order, uint32_t shift, F &&f = F()) {
+    int32_t c[T];  // wave-uniform (SGPRs): coefficient j was loaded by lane CBASE + j
 #pragma unroll
-    for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? (int32_t)sread(lpw, 2 + j) : 0;
+    for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? (int32_t)sread(lpw, CBASE + j) : 0;
     // bit e set: sample e of this lane is warm-up (lane 0 only)
     const uint32_t warm = (threadIdx.x & 63) == 0 ? ((1u << order) - 1u) : 0u;
     uint32_t ovf = 0;
@@ -2091,7 +2096,7 @@ __device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[
         uint32_t o = (uint32_t)(x[e] ^ pred) & (uint32_t)(x[e] ^ d);  // sign bit: x - pred overflowed
         if (e < 16) o &= ~(warm << (31 - e));
         ovf |= o;
-        x[e] = d;
+        x[e] = f(e, d);
         if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     return ovf >> 31;
@@ -2985,6 +2990,342 @@ __global__ void __launch_bounds__(WG) k_frame(Params p, PackParams q, uint32_t f
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Wave-per-subframe frame assembly (4096-sample frames, LPC order <= 16, <= 4 channels): the
+// workgroup is one frame, wave c is subframe c.  Lane l owns samples [64 l, 64 l + 64) in
+// registers as in k_cand64: the residual is recomputed in place (FIR with wave-uniform
+// coefficients / iterated differences), the code lengths of a lane's run are summed, one DPP scan
+// gives every lane its bit offset, and the lane then streams its codes through a 64-bit shift
+// register into the frame's LDS bit string one finished 32-bit word at a time.  The only workgroup
+// barriers are the ones around the CRC-16.
+// ---------------------------------------------------------------------------------
+struct BitRun {  // a lane's contiguous MSB-first bit run inside an LDS word array
+    uint32_t *word;   // next word to complete
+    uint64_t acc;     // pending bits, right-aligned; bits above `fill` are stale and never read
+    uint32_t fill;    // pending bit count (< 32 between calls); starts at the run's bit offset
+    __device__ __forceinline__ void init(uint32_t *sb, uint32_t pos) {
+        word = sb + (pos >> 5);
+        fill = pos & 31;  // the bits before the run belong to someone else: contribute zeros
+        acc = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb) {  // nb <= 32, v < 2^nb
+        acc = (acc << nb) | v;
+        fill += nb;
+        if (fill >= 32) {
+            fill -= 32;
+            atomicOr(word, (uint32_t)(acc >> fill));  // words at the ends of a run are shared
+            word++;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (fill) atomicOr(word, (uint32_t)(acc << (32 - fill)));
+    }
+};
+
+__device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, uint32_t ch,
+                                              uint32_t *sb, uint32_t base) {
+    const uint32_t lane = threadIdx.x & 63;
+    const SubPlan *sp = p.out_plan + (size_t)frame * p.channels + ch;
+    // One memory round trip: the whole 280-byte plan as one dword per lane (fields, coefficients
+    // and partition parameters are handed out with readlane / bpermute) and, at the same time,
+    // the samples -- for stereo frames both input rows, whatever candidate the plan names.
+    static_assert(sizeof(SubPlan) == 280, "plan layout");
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(sp);
+    const uint32_t pw = d[lane];                       // dwords 0..63
+    const uint32_t pw2 = lane < 6 ? d[64 + lane] : 0;  // dwords 64..69
+    const int32_t *rowa, *rowb;
+    if (p.stereo4) {
+        rowa = p.planar + (size_t)frame * 2 * p.ldb;
+        rowb = rowa + p.ldb;
+    } else {
+        rowa = p.planar + ((size_t)frame * p.channels + ch) * p.ldb;  // source == ch
+        rowb = rowa;
+    }
+    int32_t x[64];
+    if (p.stereo4) {
+        int4 a[16], b[16];
+        const int4 *pa = reinterpret_cast<const int4 *>(rowa) + 16 * lane;
+        const int4 *pb = reinterpret_cast<const int4 *>(rowb) + 16 * lane;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            a[q] = pa[q];
+            b[q] = pb[q];
+        }
+        const uint32_t srcid = sread(pw, 2) & 0xFF;
+        // L: a, R: b, mid: a + b (>> 1 below), side: a - b
+        const int32_t ca = srcid == 1 ? 0 : 1;
+        const int32_t cb = srcid == 0 ? 0 : srcid == FLACGPU_SRC_SIDE ? -1 : 1;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            x[4 * q] = a[q].x * ca + b[q].x * cb; x[4 * q + 1] = a[q].y * ca + b[q].y * cb;
+            x[4 * q + 2] = a[q].z * ca + b[q].z * cb; x[4 * q + 3] = a[q].w * ca + b[q].w * cb;
+        }
+    } else {
+        const int4 *pa = reinterpret_cast<const int4 *>(rowa) + 16 * lane;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int4 a = pa[q];
+            x[4 * q] = a.x; x[4 * q + 1] = a.y; x[4 * q + 2] = a.z; x[4 * q + 3] = a.w;
+        }
+    }
+    const uint32_t d0 = sread(pw, 0), d1 = sread(pw, 1), d2 = sread(pw, 2), plen = sread(pw, 4);
+    const uint32_t type = d0 & 0xFF, wasted = (d0 >> 8) & 0xFF, bps = (d0 >> 16) & 0xFF, order = d0 >> 24;
+    const uint32_t prec = d1 & 0xFF, shift = (d1 >> 8) & 0xFF, method = (d1 >> 16) & 0xFF, porder = d1 >> 24;
+    {
+        const uint32_t sh = wasted + ((p.stereo4 && (d2 & 0xFF) == FLACGPU_SRC_MID) ? 1u : 0u);
+#pragma unroll
+        for (int e = 0; e < 64; e++) x[e] >>= sh;
+    }
+    // Rice parameters of the partition this lane's 64 samples lie in (partitions are >= 64 long):
+    // rice[pj] is byte pj of dwords 38..53, escape_bits[pj] byte pj of dwords 54..69
+    const uint32_t lg = plen ? 31u - (uint32_t)__builtin_clz(plen) : 12u;
+    const uint32_t pj = (64u * lane) >> lg;
+    const bool coded = type == FLACGPU_SUB_FIXED || type == FLACGPU_SUB_LPC;
+    const uint32_t rw = __shfl(pw, (int)(38 + (pj >> 2)), 64);
+    const uint32_t ei = 54 + (pj >> 2);
+    const uint32_t ew1 = __shfl(pw, (int)(ei & 63), 64), ew2 = __shfl(pw2, (int)(ei & 63), 64);
+    const uint32_t ew = ei < 64 ? ew1 : ew2;
+    const uint32_t k = coded ? (rw >> (8 * (pj & 3))) & 0xFF : 0u;
+    const uint32_t eb = coded ? (ew >> (8 * (pj & 3))) & 0xFF : 0u;
+    const uint32_t cw = pw;  // LPC coefficient j sits on lane 6 + j
+    const uint32_t smask = bps >= 32 ? 0xFFFFFFFFu : (1u << bps) - 1u;
+    // SubframeHeader, stream.rs:1390-1413
+    if (lane == 0) {
+        const uint32_t tcode = type == FLACGPU_SUB_CONSTANT ? 0u : type == FLACGPU_SUB_VERBATIM ? 1u
+                             : type == FLACGPU_SUB_FIXED ? 8u + order : 31u + order;
+        lds_put(sb, base, tcode, 7);
+        if (wasted) {
+            lds_put(sb, base + 7, 1, 1);
+            lds_put(sb, base + 8 + (wasted - 1), 1, 1);  // wasted-1 zeros then a one
+        }
+        if (type == FLACGPU_SUB_CONSTANT) lds_put(sb, base + 8 + wasted, (uint32_t)x[0], bps);
+    }
+    const uint32_t body0 = base + 8 + wasted;
+    if (type == FLACGPU_SUB_CONSTANT) return;
+    BitRun br;
+    if (type == FLACGPU_SUB_VERBATIM) {
+        br.init(sb, body0 + lane * 64u * bps);
+#pragma unroll
+        for (int e = 0; e < 64; e++) br.put((uint32_t)x[e] & smask, bps);
+        br.finish();
+        return;
+    }
+    // warm-up samples (encode.rs:3083-3085, 3118-3133): the first `order` samples of lane 0
+    if (lane == 0) {
+        br.init(sb, body0);
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            if ((uint32_t)e < order) br.put((uint32_t)x[e] & smask, bps);
+        br.finish();
+    }
+    // Code lengths are summed where each residual is produced; Rice-coded lanes keep zigzag(r)
+    // in place of r.  Warm-up samples (lane 0, e < order) carry no residual.
+    const uint32_t first = lane == 0 ? order : 0u;
+    const bool rice = k != 0xFF;
+    struct LenAcc {
+        uint32_t qsum, ks, first;
+        bool rice;
+        __device__ __forceinline__ int32_t operator()(int e, int32_t r) {
+            uint32_t u = zigzag(r);
+            if (e < 16) u = (uint32_t)e >= first ? u : 0u;
+            qsum += u >> ks;
+            return rice ? (int32_t)u : r;
+        }
+    } len{0u, rice ? k : 0u, first, rice};
+    uint32_t resid_pos = body0 + order * bps;
+    if (type == FLACGPU_SUB_LPC) {
+        if (lane == 32) {
+            lds_put(sb, resid_pos, prec - 1, 4);
+            lds_put(sb, resid_pos + 4, shift, 5);
+        }
+        if (lane >= 6 && lane < 6 + order) lds_put(sb, resid_pos + 9 + (lane - 6) * prec, cw, prec);
+        resid_pos += 9 + order * prec;
+        int32_t hp[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) hp[kk] = lane_prev(x[48 + kk]);
+        switch ((order + 3) >> 2) {  // the residual, in place (encode.rs:3181-3197)
+        case 1: fir64<4, 6>(x, hp, cw, order, shift, len); break;
+        case 2: fir64<8, 6>(x, hp, cw, order, shift, len); break;
+        case 3: fir64<12, 6>(x, hp, cw, order, shift, len); break;
+        default: fir64<16, 6>(x, hp, cw, order, shift, len); break;
+        }
+    } else {  // FIXED: iterated differences in place (encode.rs:3039-3060)
+        int32_t h[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int32_t t = __shfl_up(x[60 + kk], 1, 64);
+            h[kk] = lane ? t : 0;
+        }
+        int32_t q0 = h[3], q1 = h[3] - h[2], q2 = q1 - (h[2] - h[1]);
+        int32_t q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
+#pragma unroll
+        for (int e = 0; e < 64; e++) {
+            const int32_t e1 = x[e] - q0, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
+            q0 = x[e]; q1 = e1; q2 = e2; q3 = e3;
+            x[e] = len(e, order == 0 ? x[e] : order == 1 ? e1 : order == 2 ? e2 : order == 3 ? e3 : e4);
+            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // residual block (encode.rs:3944-3961, 3898-3907)
+    const uint32_t hb = method ? 5u : 4u, esc_code = method ? 31u : 15u;
+    if (lane == 1) {
+        lds_put(sb, resid_pos, method, 2);
+        lds_put(sb, resid_pos + 2, porder, 4);
+    }
+    const uint32_t pos = resid_pos + 6;
+    const bool head = ((64u * lane) & (plen - 1u)) == 0;   // this lane starts a partition
+    const uint32_t cnt = 64u - first;
+    const uint32_t mybits = (head ? hb + (rice ? 0u : 5u) : 0u) + (rice ? len.qsum + cnt * (k + 1u) : cnt * eb);
+    const uint32_t incl = wave_scan_u32(mybits);
+    br.init(sb, pos + incl - mybits);
+    if (head) {
+        if (rice) br.put(k, hb);
+        else { br.put(esc_code, hb); br.put(eb, 5); }
+    }
+    if (rice) {
+        const uint32_t stop = 1u << k, lowmask = stop - 1u;
+#pragma unroll
+        for (int e = 0; e < 64; e++) {
+            if (e >= 16 || (uint32_t)e >= first) {
+                const uint32_t u = (uint32_t)x[e];
+                uint32_t qn = u >> k;
+                const uint32_t v = stop | (u & lowmask);
+                if (qn + k + 1u > 32u) {  // long unary run: zeros in pieces
+                    while (qn >= 32u) { br.put(0, 32); qn -= 32u; }
+                    br.put(0, qn);
+                    br.put(v, k + 1u);
+                } else {
+                    br.put(v, qn + k + 1u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (eb) {
+        const uint32_t emask = eb >= 32 ? 0xFFFFFFFFu : (1u << eb) - 1u;
+#pragma unroll
+        for (int e = 0; e < 64; e++)
+            if (e >= 16 || (uint32_t)e >= first) br.put((uint32_t)x[e] & emask, eb);
+    }
+    br.finish();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ uint16_t T[4][256];  // slicing-by-4 tables
+    __shared__ uint32_t part[4];
+    __shared__ uint8_t hdr[16];
+    const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
+    const uint32_t ch = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *fb = reinterpret_cast<uint32_t *>(lds);
+    const uint64_t fn = q.first_frame_number + frame;
+    const HeaderCodes hc = header_codes(FN, q.sample_rate, fn);
+    const uint64_t begin = q.frame_off[frame];
+    const uint32_t flen = (uint32_t)(q.frame_off[frame + 1] - begin);  // bytes, CRC-16 included
+    const uint32_t nwords = (flen + 3) / 4 + 1;
+    for (uint32_t i = tid; i < nwords; i += NT) fb[i] = 0;
+    for (uint32_t b = tid; b < 256; b += NT) {
+        uint32_t c = b << 8;
+        for (int kk = 0; kk < 4; kk++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
+            for (int i = 0; i < 8; i++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
+            T[kk][b] = (uint16_t)c;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
+        const flacgpu_frame_plan fp = p.frame_plan[frame];
+        uint32_t kk = 0;
+        hdr[kk++] = 0xFF;
+        hdr[kk++] = 0xF8;  // sync 0b111111111111100 + blocking strategy 0
+        hdr[kk++] = (uint8_t)((hc.bcode << 4) | hc.rcode);
+        const uint32_t acode = fp.assignment == FLACGPU_ASSIGN_INDEPENDENT ? p.channels - 1 : fp.assignment;
+        const uint32_t pcode = p.bps == 8 ? 1 : p.bps == 12 ? 2 : p.bps == 16 ? 4 : p.bps == 20 ? 5
+                             : p.bps == 24 ? 6 : p.bps == 32 ? 7 : 0;
+        hdr[kk++] = (uint8_t)((acode << 4) | (pcode << 1));
+        if (hc.fn_bytes == 1) {
+            hdr[kk++] = (uint8_t)fn;
+        } else {  // UTF-8-like frame number, stream.rs:1264-1325
+            const uint32_t nb = hc.fn_bytes;
+            const uint32_t lead = (0xFFu << (8 - nb)) & 0xFF;
+            hdr[kk++] = (uint8_t)(lead | (uint32_t)(fn >> (6 * (nb - 1))));
+            for (int b = (int)nb - 2; b >= 0; b--) hdr[kk++] = (uint8_t)(0x80 | ((fn >> (6 * b)) & 0x3F));
+        }
+        if (hc.bextra_bits == 8) hdr[kk++] = (uint8_t)(FN - 1);
+        else if (hc.bextra_bits == 16) { hdr[kk++] = (uint8_t)((FN - 1) >> 8); hdr[kk++] = (uint8_t)(FN - 1); }
+        if (hc.rextra_bits == 8) hdr[kk++] = (uint8_t)hc.rextra;
+        else if (hc.rextra_bits == 16) { hdr[kk++] = (uint8_t)(hc.rextra >> 8); hdr[kk++] = (uint8_t)hc.rextra; }
+        uint32_t crc = 0;  // CRC-8, poly 0x07 (crc.rs:99-128)
+        for (uint32_t i = 0; i < kk; i++) {
+            crc ^= hdr[i];
+            for (int b = 0; b < 8; b++) crc = (crc & 0x80) ? ((crc << 1) ^ 0x07) & 0xFF : (crc << 1) & 0xFF;
+        }
+        hdr[kk++] = (uint8_t)crc;
+        for (uint32_t i = 0; i < kk; i++) lds_put(fb, 8 * i, hdr[i], 8);
+    }
+    uint32_t start_bit = header_bytes(hc) * 8;
+    for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
+    wave_subframe(p, frame, ch, fb, start_bit);
+    __syncthreads();
+    // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4))
+    const uint32_t len = flen - 2;
+    constexpr uint32_t CH = NT * 68;                 // bytes per pass
+    const uint32_t my_weight = kCrcW17.w[NT - 1 - tid];
+    const uint32_t xchunk = kCrcW17.w[NT];
+    uint32_t running = 0;
+    for (uint32_t pos = 0; pos < len;) {
+        const uint32_t clen = (pos == 0 && (len % CH)) ? len % CH : CH;
+        const int32_t f0 = (int32_t)pos - (int32_t)(CH - clen) + (int32_t)(68 * tid);
+        const int32_t w0 = f0 >> 2;
+        const uint32_t sh = ((uint32_t)f0 & 3u) * 8u;
+        uint32_t crc = 0;
+        uint32_t cur = w0 >= 0 ? fb[w0] : 0u;
+#pragma unroll
+        for (int kk = 0; kk < 17; kk++) {
+            const int32_t wn = w0 + kk + 1;
+            const uint32_t nxt = wn >= 0 ? fb[wn] : 0u;
+            const uint32_t m = sh ? (cur << sh) | (nxt >> (32 - sh)) : cur;
+            crc = T[3][((crc >> 8) ^ (m >> 24)) & 0xFF] ^ T[2][(crc ^ (m >> 16)) & 0xFF] ^
+                  T[1][(m >> 8) & 0xFF] ^ T[0][m & 0xFF];
+            cur = nxt;
+        }
+        uint32_t c = gf_mulmod(crc, my_weight);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c ^= __shfl_xor(c, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) part[tid >> 6] = c;
+        __syncthreads();
+        uint32_t all = 0;
+#pragma unroll
+        for (int wv = 0; wv < NT / 64; wv++) all ^= part[wv];
+        running = gf_mulmod(running, xchunk) ^ all;
+        pos += clen;
+    }
+    if (tid == 0) {  // the two CRC bytes follow byte len - 1 (still zero there)
+        atomicOr(&fb[len >> 2], ((running >> 8) & 0xFF) << (24 - 8 * (len & 3)));
+        atomicOr(&fb[(len + 1) >> 2], (running & 0xFF) << (24 - 8 * ((len + 1) & 3)));
+    }
+    __syncthreads();
+    // ---- copy out: output dword j covers frame bytes [4 j - r, 4 j - r + 4)
+    uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
+    const uint32_t r = (uint32_t)(begin & 3);
+    uint32_t *og = reinterpret_cast<uint32_t *>(ob + (begin - r));
+    const uint32_t nout = (r + flen + 3) / 4;
+    for (uint32_t j = tid; j < nout; j += NT) {
+        const uint32_t hi = (r && j == 0) ? 0u : fb[j - (r ? 1u : 0u)];
+        const uint32_t m = r ? (hi << (8 * (4 - r))) | (fb[j] >> (8 * r)) : hi;  // MSB-first window
+        const int32_t fbyte = (int32_t)(4 * j) - (int32_t)r;
+        if (fbyte >= 0 && fbyte + 4 <= (int32_t)flen) {
+            og[j] = __builtin_bswap32(m);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int32_t fbk = fbyte + e;
+                if (fbk >= 0 && fbk < (int32_t)flen) ob[begin + fbk] = (uint8_t)(m >> (24 - 8 * e));
+            }
+        }
+    }
+}
+
 // VERIFY = false: store the CRC-16 behind the frame; true: compare with the stored one and
 // count mismatching frames in verify_counts[1]
 template <bool VERIFY>
@@ -3805,7 +4146,17 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     if (c->timing) (void)hipEventRecord(ev[1], st);
     {
         const size_t lds = pack_lds_bytes(p.block_size);
-        if (pf.fcount && fused) {
+        const bool f64w = fused && p.max_lpc_order <= 16 && p.channels <= 4 && p.max_po <= 6 &&
+                          !getenv("FLACGPU_NO_FRAME64");
+        if (pf.fcount && f64w) {  // wave per subframe
+            const size_t l64 = (size_t)fbw * sizeof(int32_t);
+            switch (p.channels) {
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64>), dim3(pf.fcount), dim3(64), l64, st, pf, q); break;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128>), dim3(pf.fcount), dim3(128), l64, st, pf, q); break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192>), dim3(pf.fcount), dim3(192), l64, st, pf, q); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256>), dim3(pf.fcount), dim3(256), l64, st, pf, q); break;
+            }
+        } else if (pf.fcount && fused) {
             if (p.max_lpc_order <= 16)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<1>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
             else
