@@ -2890,6 +2890,21 @@ struct CrcWeights17 {
 };
 __constant__ CrcWeights17 kCrcW17 = CrcWeights17();
 
+// slicing-by-4 tables of the CRC-16: T[k][b] = CRC state after byte b followed by k zero bytes
+struct CrcTables {
+    uint16_t t[4][256];
+    constexpr CrcTables() : t() {
+        for (int b = 0; b < 256; b++) {
+            uint32_t c = (uint32_t)b << 8;
+            for (int k = 0; k < 4; k++) {
+                for (int i = 0; i < 8; i++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
+                t[k][b] = (uint16_t)c;
+            }
+        }
+    }
+};
+__constant__ __attribute__((aligned(16))) CrcTables kCrcT = CrcTables();
+
 // words of LDS a whole frame of 4096-sample subframes may need (VERBATIM everywhere + header +
 // CRC-16 + one guard word for the funnel shifts); multiple of 4 words
 __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps) {
@@ -3212,7 +3227,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
 template <int NT>
 __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ uint16_t T[4][256];  // slicing-by-4 tables
+    __shared__ __attribute__((aligned(16))) uint16_t T[4][256];  // slicing-by-4 tables
     __shared__ uint32_t part[4];
     __shared__ uint8_t hdr[16];
     const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
@@ -3223,14 +3238,9 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     const uint64_t begin = q.frame_off[frame];
     const uint32_t flen = (uint32_t)(q.frame_off[frame + 1] - begin);  // bytes, CRC-16 included
     const uint32_t nwords = (flen + 3) / 4 + 1;
-    for (uint32_t i = tid; i < nwords; i += NT) fb[i] = 0;
-    for (uint32_t b = tid; b < 256; b += NT) {
-        uint32_t c = b << 8;
-        for (int kk = 0; kk < 4; kk++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
-            for (int i = 0; i < 8; i++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
-            T[kk][b] = (uint16_t)c;
-        }
-    }
+    for (uint32_t i = tid; i < (nwords + 3) / 4; i += NT) reinterpret_cast<uint4 *>(fb)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < 128; i += NT)
+        reinterpret_cast<uint4 *>(&T[0][0])[i] = reinterpret_cast<const uint4 *>(&kCrcT.t[0][0])[i];
     __syncthreads();
     if (tid == 0) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
         const flacgpu_frame_plan fp = p.frame_plan[frame];
@@ -3264,41 +3274,59 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     }
     uint32_t start_bit = header_bytes(hc) * 8;
     for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
-    wave_subframe(p, frame, ch, fb, start_bit);
+    if (!(p.dbg & 2)) wave_subframe(p, frame, ch, fb, start_bit);
     __syncthreads();
-    // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4))
-    const uint32_t len = flen - 2;
-    constexpr uint32_t CH = NT * 68;                 // bytes per pass
-    const uint32_t my_weight = kCrcW17.w[NT - 1 - tid];
-    const uint32_t xchunk = kCrcW17.w[NT];
+    // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4)).
+    // One pass: the frame, left-padded with zero bytes (they leave a zero CRC state unchanged) to
+    // S * NT slices of 17 words, slice g = s * NT + tid; a lane runs its S <= 3 table-lookup chains
+    // interleaved (each step is one LDS round trip), folds them with Horner in x^(544 NT) and the
+    // lanes' results are combined with the weights x^(544 (NT - 1 - tid)) (GF(2) linearity).
+    const uint32_t len = (p.dbg & 4) ? 0 : flen - 2;
+    constexpr uint32_t CH = NT * 68;                 // bytes per slice row
+    const uint32_t S = (len + CH - 1) / CH;          // 1..3 (frame_fb_words bounds the frame)
+    const uint32_t padb = S * CH - len;
     uint32_t running = 0;
-    for (uint32_t pos = 0; pos < len;) {
-        const uint32_t clen = (pos == 0 && (len % CH)) ? len % CH : CH;
-        const int32_t f0 = (int32_t)pos - (int32_t)(CH - clen) + (int32_t)(68 * tid);
-        const int32_t w0 = f0 >> 2;
-        const uint32_t sh = ((uint32_t)f0 & 3u) * 8u;
-        uint32_t crc = 0;
-        uint32_t cur = w0 >= 0 ? fb[w0] : 0u;
+    auto chains = [&](auto sc) {
+        constexpr int SC = decltype(sc)::value;
+        uint32_t crc[SC], cur[SC], sh[SC];
+        int32_t w0[SC];
+#pragma unroll
+        for (int c = 0; c < SC; c++) {
+            const int32_t f0 = (int32_t)((c * NT + tid) * 68) - (int32_t)padb;  // first frame byte of the slice
+            w0[c] = f0 >> 2;                         // floor: f0 may be negative
+            sh[c] = ((uint32_t)f0 & 3u) * 8u;
+            crc[c] = 0;
+            cur[c] = w0[c] >= 0 ? fb[w0[c]] : 0u;
+        }
 #pragma unroll
         for (int kk = 0; kk < 17; kk++) {
-            const int32_t wn = w0 + kk + 1;
-            const uint32_t nxt = wn >= 0 ? fb[wn] : 0u;
-            const uint32_t m = sh ? (cur << sh) | (nxt >> (32 - sh)) : cur;
-            crc = T[3][((crc >> 8) ^ (m >> 24)) & 0xFF] ^ T[2][(crc ^ (m >> 16)) & 0xFF] ^
-                  T[1][(m >> 8) & 0xFF] ^ T[0][m & 0xFF];
-            cur = nxt;
+#pragma unroll
+            for (int c = 0; c < SC; c++) {
+                const int32_t wn = w0[c] + kk + 1;
+                const uint32_t nxt = wn >= 0 ? fb[wn] : 0u;
+                const uint32_t m = sh[c] ? (cur[c] << sh[c]) | (nxt >> (32 - sh[c])) : cur[c];
+                crc[c] = T[3][((crc[c] >> 8) ^ (m >> 24)) & 0xFF] ^ T[2][(crc[c] ^ (m >> 16)) & 0xFF] ^
+                         T[1][(m >> 8) & 0xFF] ^ T[0][m & 0xFF];
+                cur[c] = nxt;
+            }
         }
-        uint32_t c = gf_mulmod(crc, my_weight);
+        const uint32_t xrow = kCrcW17.w[NT];          // x^(544 NT)
+        uint32_t acc = crc[0];
+#pragma unroll
+        for (int c = 1; c < SC; c++) acc = gf_mulmod(acc, xrow) ^ crc[c];
+        return acc;
+    };
+    if (S) {
+        uint32_t c = S == 1 ? chains(std::integral_constant<int, 1>{})
+                   : S == 2 ? chains(std::integral_constant<int, 2>{})
+                            : chains(std::integral_constant<int, 3>{});
+        c = gf_mulmod(c, kCrcW17.w[NT - 1 - tid]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c ^= __shfl_xor(c, off, 64);
-        __syncthreads();
         if ((tid & 63) == 0) part[tid >> 6] = c;
         __syncthreads();
-        uint32_t all = 0;
 #pragma unroll
-        for (int wv = 0; wv < NT / 64; wv++) all ^= part[wv];
-        running = gf_mulmod(running, xchunk) ^ all;
-        pos += clen;
+        for (int wv = 0; wv < NT / 64; wv++) running ^= part[wv];
     }
     if (tid == 0) {  // the two CRC bytes follow byte len - 1 (still zero there)
         atomicOr(&fb[len >> 2], ((running >> 8) & 0xFF) << (24 - 8 * (len & 3)));
@@ -3309,10 +3337,9 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
     const uint32_t r = (uint32_t)(begin & 3);
     uint32_t *og = reinterpret_cast<uint32_t *>(ob + (begin - r));
-    const uint32_t nout = (r + flen + 3) / 4;
-    for (uint32_t j = tid; j < nout; j += NT) {
-        const uint32_t hi = (r && j == 0) ? 0u : fb[j - (r ? 1u : 0u)];
-        const uint32_t m = r ? (hi << (8 * (4 - r))) | (fb[j] >> (8 * r)) : hi;  // MSB-first window
+    const uint32_t nout = (p.dbg & 8) ? 0 : (r + flen + 3) / 4;
+    auto emit = [&](uint32_t j, uint32_t hi, uint32_t lo) {
+        const uint32_t m = r ? (hi << (8 * (4 - r))) | (lo >> (8 * r)) : hi;  // MSB-first window
         const int32_t fbyte = (int32_t)(4 * j) - (int32_t)r;
         if (fbyte >= 0 && fbyte + 4 <= (int32_t)flen) {
             og[j] = __builtin_bswap32(m);
@@ -3323,6 +3350,20 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
                 if (fbk >= 0 && fbk < (int32_t)flen) ob[begin + fbk] = (uint8_t)(m >> (24 - 8 * e));
             }
         }
+    };
+    const uint32_t back = r ? 1u : 0u;
+    for (uint32_t j0 = tid; j0 < nout; j0 += 4 * NT) {  // four independent LDS round trips in flight
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = j0 + u * NT;
+            const bool in = j < nout;
+            hi[u] = (in && !(r && j == 0)) ? fb[j - back] : 0u;
+            lo[u] = in ? fb[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (j0 + u * NT < nout) emit(j0 + u * NT, hi[u], lo[u]);
     }
 }
 
