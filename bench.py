@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES, help="FLAC frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=3, choices=(1, 2, 3, 4),
+                    help="encoder contexts consecutive batches rotate through (multi-buffering)")
     args = ap.parse_args()
 
     import torch
@@ -79,10 +81,23 @@ def main():
     an = GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
                      device=local_rank)
     first_frame = rank * F                          # contiguous frame ranges per GPU (8(e))
+    # Multi-buffering, as a streaming encoder runs: consecutive batches rotate through a few
+    # encoder contexts (each with its own plans / output buffer in HBM) on their own HIP streams,
+    # so the HBM-bound, latency-bound and VALU-bound kernels of neighbouring batches overlap; a
+    # context's output stays valid until the context is used again.  --contexts 1 runs every
+    # batch back to back on one context.
+    ans = [an]
+    for _ in range(args.contexts - 1):
+        ans.append(GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
+                               device=local_rank))
+    streams = [torch.cuda.Stream() for _ in ans]
+    step_no = [0]
 
-    def step():
-        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
-        an.pack_device(first_frame, RATE)
+    def step():   # analysis + frame assembly of one whole batch (flacgpu_encode_device)
+        i = step_no[0] % len(ans)
+        step_no[0] += 1
+        ans[i].encode_device(d_pcm.data_ptr(), F, BLOCK, first_frame, RATE,
+                             stream=streams[i].cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -264,7 +279,8 @@ def main():
                                    "LPC order 12, partition order 6, mid-side, exhaustive), "
                                    f"{F} frames per GPU per step, PCM resident in HBM, frame bytes "
                                    "produced in HBM",
-                       "frames_per_gpu": F, "parallelism": f"frame ranges x{world}"},
+                       "frames_per_gpu": F, "parallelism": f"frame ranges x{world}",
+                       "contexts": len(ans)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
@@ -275,7 +291,8 @@ def main():
             "parity_checked_frames": check,
             "shard_counters": counters,
         }
-    an.close()
+    for a in ans:
+        a.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -531,8 +531,8 @@ __global__ void __launch_bounds__(WG) k_deinterleave(const int32_t *__restrict__
                                                      int32_t *__restrict__ out, uint32_t channels,
                                                      uint32_t block_size, uint32_t ldb,
                                                      uint32_t n_frames, uint32_t last_len,
-                                                     int planar_in) {
-    const uint32_t frame = blockIdx.y;
+                                                     int planar_in, uint32_t f0) {
+    const uint32_t frame = f0 + blockIdx.y;
     const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
     const size_t in_base = (size_t)frame * block_size * channels;
     int32_t *o = out + (size_t)frame * channels * ldb;
@@ -552,8 +552,9 @@ __global__ void __launch_bounds__(WG) k_deinterleave2(const int2 *__restrict__ i
                                                       int32_t *__restrict__ out,
                                                       uint32_t block_size, uint32_t ldb,
                                                       uint32_t n_frames, uint32_t last_len,
-                                                      uint32_t *__restrict__ orbits, uint32_t ncand) {
-    const uint32_t frame = blockIdx.y;
+                                                      uint32_t *__restrict__ orbits, uint32_t ncand,
+                                                      uint32_t f0) {
+    const uint32_t frame = f0 + blockIdx.y;
     const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
     const int2 *src = in + (size_t)frame * block_size;
     int32_t *o = out + (size_t)frame * 2 * ldb;
@@ -584,7 +585,7 @@ __global__ void __launch_bounds__(WG) k_deinterleave2(const int2 *__restrict__ i
 
 // the same ORs from the planar buffer (every layout but interleaved stereo)
 __global__ void __launch_bounds__(WG) k_orbits(Params p, uint32_t *__restrict__ orbits) {
-    const uint32_t frame = blockIdx.y;
+    const uint32_t frame = p.f0 + blockIdx.y;
     const uint32_t n = frame_len(p, frame);
     const int32_t *base = p.planar + (size_t)frame * p.channels * p.ldb;
     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -610,8 +611,8 @@ __global__ void __launch_bounds__(WG) k_orbits(Params p, uint32_t *__restrict__ 
 
 // per (frame, candidate): activity, wasted bits, effective bps (encode.rs:2870-2898)
 __global__ void __launch_bounds__(WG) k_candinfo(Params p, const uint32_t *__restrict__ orbits) {
-    const uint32_t idx = blockIdx.x * WG + threadIdx.x;
-    if (idx >= p.n_frames * p.ncand) return;
+    const uint32_t idx = p.f0 * p.ncand + blockIdx.x * WG + threadIdx.x;
+    if (idx >= (p.f0 + p.fcount) * p.ncand) return;
     const uint32_t cand = idx % p.ncand;
     CandInfo ci;
     if (p.exhaustive || !p.stereo4)
@@ -640,7 +641,7 @@ __global__ void __launch_bounds__(WG) k_candinfo(Params p, const uint32_t *__res
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WG) k_stereo_stats(Params p) {
     __shared__ uint64_t red[4];
-    const uint32_t frame = blockIdx.x;
+    const uint32_t frame = p.f0 + blockIdx.x;
     const uint32_t n = frame_len(p, frame);
     const int32_t *L = p.planar + (size_t)frame * 2 * p.ldb;
     const int32_t *R = L + p.ldb;
@@ -1283,8 +1284,8 @@ __device__ __forceinline__ long long total_key(double x) {  // f64::total_cmp ke
 }
 
 __global__ void __launch_bounds__(64) k_lpc(Params p) {
-    const uint32_t idx = blockIdx.x * 64 + threadIdx.x;
-    if (idx >= p.n_frames * p.ncand) return;
+    const uint32_t idx = p.f0 * p.ncand + blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (p.f0 + p.fcount) * p.ncand) return;
     const uint32_t frame = idx / p.ncand;
     const uint32_t n = frame_len(p, frame);
     const CandInfo ci = p.cinfo[idx];
@@ -2285,7 +2286,7 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
 // K6: channel-assignment choice, one wave per frame (lane 0 decides, the wave copies)
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_decide(Params p) {
-    const uint32_t frame = blockIdx.x;
+    const uint32_t frame = p.f0 + blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t n = frame_len(p, frame);
     const SubPlan *cp = p.cand_plan + (size_t)frame * p.ncand;
@@ -2464,18 +2465,22 @@ __device__ __forceinline__ uint32_t header_bytes(const HeaderCodes &h) {
     return 4 + h.fn_bytes + h.bextra_bits / 8 + h.rextra_bits / 8 + 1;
 }
 
+// frames [p.f0, p.f0 + p.fcount): byte offsets continue from frame_off[p.f0] (0 for the first
+// range; written by the previous range's launch otherwise)
 __global__ void __launch_bounds__(1024) k_layout(Params p, PackParams q) {
     __shared__ uint64_t wave_tot[16];
     const uint32_t tid = threadIdx.x;
     // lane t owns the contiguous frames [t*chunk, (t+1)*chunk): serial sum, one block scan
-    const uint32_t chunk = (p.n_frames + 1023) / 1024;
-    const uint32_t lo = tid * chunk;
-    const uint32_t hi = lo + chunk < p.n_frames ? lo + chunk : p.n_frames;
+    const uint32_t chunk = (p.fcount + 1023) / 1024;
+    const uint32_t end = p.f0 + p.fcount;
+    const uint32_t lo = p.f0 + tid * chunk < end ? p.f0 + tid * chunk : end;
+    const uint32_t hi = lo + chunk < end ? lo + chunk : end;
     auto frame_bytes = [&](uint32_t f) -> uint64_t {
         const flacgpu_frame_plan fp = p.frame_plan[f];
         HeaderCodes h = header_codes(fp.block_size, q.sample_rate, q.first_frame_number + f);
         return header_bytes(h) + ((uint64_t)fp.body_bits + 7) / 8 + 2;
     };
+    const uint64_t base = p.f0 ? q.frame_off[p.f0] : 0ull;
     uint64_t mine = 0;
     for (uint32_t f = lo; f < hi; f++) mine += frame_bytes(f);
     uint64_t v = mine;
@@ -2486,13 +2491,13 @@ __global__ void __launch_bounds__(1024) k_layout(Params p, PackParams q) {
     }
     if ((tid & 63) == 63) wave_tot[tid >> 6] = v;
     __syncthreads();
-    uint64_t prefix = v - mine;
+    uint64_t prefix = base + v - mine;
     for (uint32_t w = 0; w < (tid >> 6); w++) prefix += wave_tot[w];
     for (uint32_t f = lo; f < hi; f++) {
-        q.frame_off[f] = prefix;
+        if (f != p.f0 || p.f0 == 0) q.frame_off[f] = prefix;
         prefix += frame_bytes(f);
     }
-    if (tid == 1023) q.frame_off[p.n_frames] = prefix;
+    if (tid == 1023) q.frame_off[end] = prefix;
 }
 
 // zero the part of the output buffer the frames will occupy (16 bytes per lane)
@@ -3681,7 +3686,8 @@ struct flacgpu_ctx {
     int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
     uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_layout = nullptr;
+    bool two_ranges = false;         // flacgpu_set_two_ranges
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
     uint64_t packed_cap = 0;        // bytes
@@ -3889,6 +3895,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_layout, hipEventDisableTiming));
     HIP_TRY(hipMemsetAsync(c->d_planar, 0, sizeof(int32_t) * (F * C * c->ldb + slack), c->own_stream));
     HIP_TRY(hipMemsetAsync(c->d_cinfo, 0, sizeof(CandInfo) * F * NC, c->own_stream));
     double thr[128];
@@ -3920,6 +3927,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_layout) (void)hipEventDestroy(c->ev_layout);
     if (c->ev_ok) for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -3931,28 +3939,8 @@ int flacgpu_set_timing(flacgpu_ctx *c, int enable) {
     return 0;
 }
 
-int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
-                           uint32_t last_len, void *stream) {
-    if (!c || !d_pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
-        last_len > c->opts.block_size || (layout != 0 && layout != 1)) {
-        g_last_error = "invalid analyze arguments";
-        return FLACGPU_ERR_INVALID_ARG;
-    }
+static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_len, Params &p) {
     const uint32_t B = c->opts.block_size;
-    // the reference collects partitions into ArrayVec<_, 64> and panics beyond (encode.rs:3880)
-    for (uint32_t n : {n_frames > 1 ? B : last_len, last_len}) {
-        uint32_t tz = (uint32_t)__builtin_ctz(n);
-        if ((tz < c->opts.max_partition_order ? tz : c->opts.max_partition_order) > (uint32_t)MAXP) {
-            g_last_error = "effective partition order > 6: the reference panics (MAX_PARTITIONS = 64)";
-            return FLACGPU_ERR_UNSUPPORTED;
-        }
-    }
-    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
-    if (last_len != B && last_len != c->window_last_len) {
-        if (int rc = upload_window(c, last_len, c->d_window_last, st)) return rc;
-        c->window_last_len = last_len;
-    }
-    Params p;
     memset(&p, 0, sizeof p);
     p.channels = c->channels;
     p.bps = c->bps;
@@ -3985,6 +3973,32 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     p.residuals = c->d_resid;
     p.stats = c->d_stats;
 
+}
+
+int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                           uint32_t last_len, void *stream) {
+    if (!c || !d_pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size || (layout != 0 && layout != 1)) {
+        g_last_error = "invalid analyze arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const uint32_t B = c->opts.block_size;
+    // the reference collects partitions into ArrayVec<_, 64> and panics beyond (encode.rs:3880)
+    for (uint32_t n : {n_frames > 1 ? B : last_len, last_len}) {
+        uint32_t tz = (uint32_t)__builtin_ctz(n);
+        if ((tz < c->opts.max_partition_order ? tz : c->opts.max_partition_order) > (uint32_t)MAXP) {
+            g_last_error = "effective partition order > 6: the reference panics (MAX_PARTITIONS = 64)";
+            return FLACGPU_ERR_UNSUPPORTED;
+        }
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    if (last_len != B && last_len != c->window_last_len) {
+        if (int rc = upload_window(c, last_len, c->d_window_last, st)) return rc;
+        c->window_last_len = last_len;
+    }
+    Params p;
+    fill_params(c, n_frames, last_len, p);
+
     int evi = 0;
     for (auto &u : c->ev_used) u = false;
     auto mark = [&](int k) {  // event BEFORE kernel k; the next mark closes it
@@ -4014,11 +4028,11 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames);  // 8 samples per lane
         if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
             hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm,
-                               c->d_planar, B, c->ldb, n_frames, last_len, c->d_orbits, c->ncand);
+                               c->d_planar, B, c->ldb, n_frames, last_len, c->d_orbits, c->ncand, 0u);
             have_orbits = true;
         } else {
             hipLaunchKernelGGL(k_deinterleave, grid, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels,
-                               B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR);
+                               B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR, 0u);
         }
     }
     if (!have_orbits)
@@ -4238,6 +4252,106 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     return FLACGPU_OK;
 }
 
+int flacgpu_set_two_ranges(flacgpu_ctx *c, int on) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    c->two_ranges = on != 0;
+    return FLACGPU_OK;
+}
+
+// Analysis + frame assembly of one batch in one call.  With flacgpu_set_two_ranges(ctx, 1), when
+// every frame takes the wave kernels (4096-sample blocks, order <= 16, <= 4 channels), the batch
+// is cut into two frame ranges that run
+// the whole kernel chain on two HIP streams: the HBM-bound (K0, copy-out), latency-bound (Levinson,
+// layout, CRC) and VALU-bound (autocorrelation, k_cand64, k_frame64) kernels of the two ranges
+// overlap instead of running back to back.  The second range's byte offsets continue from the first
+// range's total (k_layout), so the output is the same contiguous byte string.  Anything else runs
+// flacgpu_analyze_device + flacgpu_pack_device.
+int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                          uint32_t last_len, uint64_t first_frame_number, uint32_t sample_rate,
+                          void *stream) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    const uint32_t B = c->opts.block_size;
+    const uint32_t fbw = frame_fb_words(c->channels, c->bps);
+    const bool eligible =
+        d_pcm && n_frames >= 256 && n_frames <= c->max_frames && last_len == B && B == FN &&
+        (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && c->opts.max_lpc_order <= 16 &&
+        c->opts.max_partition_order <= 6 && c->channels <= 4 && (layout == 0 || layout == 1) &&
+        (size_t)fbw * sizeof(int32_t) <= 64 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
+        !getenv("FLACGPU_NO_W64") && !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64") &&
+        c->two_ranges;
+    if (!eligible) {
+        if (int rc = flacgpu_analyze_device(c, d_pcm, layout, n_frames, last_len, stream)) return rc;
+        return flacgpu_pack_device(c, first_frame_number, sample_rate, stream);
+    }
+    hipStream_t st0 = stream ? (hipStream_t)stream : c->own_stream;
+    hipStream_t st1 = c->aux_stream;
+    Params p;
+    fill_params(c, n_frames, last_len, p);
+    PackParams q;
+    q.first_frame_number = first_frame_number;
+    q.sample_rate = sample_rate;
+    q.out_words = c->d_packed;
+    q.frame_off = c->d_frame_off;
+    q.cap_bytes = c->packed_cap;
+    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0);
+    if (planar_direct) p.planar = d_pcm;
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(uint32_t), st0));
+    HIP_TRY(hipMemsetAsync(c->d_orbits, 0, sizeof(uint32_t) * n_frames * c->ncand, st0));
+    HIP_TRY(hipEventRecord(c->ev_fork, st0));
+    HIP_TRY(hipStreamWaitEvent(st1, c->ev_fork, 0));
+    const uint32_t h = ((n_frames / 2) + 15u) & ~15u;  // 16 frames = one autocorrelation wave group
+    const bool lpc = p.max_lpc_order > 0;
+    const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
+    const size_t l64 = (size_t)fbw * sizeof(int32_t);
+    for (int half = 0; half < 2; half++) {
+        hipStream_t st = half ? st1 : st0;
+        Params r = p;
+        r.f0 = half ? h : 0;
+        r.fcount = half ? n_frames - h : h;
+        const uint32_t ncb = r.fcount * c->ncand;
+        const dim3 g0(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), r.fcount);
+        bool have_orbits = false;
+        if (!planar_direct) {
+            if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
+                hipLaunchKernelGGL(k_deinterleave2, g0, dim3(WG), 0, st, (const int2 *)d_pcm, c->d_planar, B,
+                                   c->ldb, n_frames, last_len, c->d_orbits, c->ncand, r.f0);
+                have_orbits = true;
+            } else {
+                hipLaunchKernelGGL(k_deinterleave, g0, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels, B,
+                                   c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR, r.f0);
+            }
+        }
+        if (!have_orbits) hipLaunchKernelGGL(k_orbits, g0, dim3(WG), 0, st, r, c->d_orbits);
+        if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats, dim3(r.fcount), dim3(WG), 0, st, r);
+        hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits);
+        if (lpc) {
+            dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
+            hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, r);
+        }
+        hipLaunchKernelGGL(k_cand64, dim3((ncb + 3) / 4), dim3(WG), 0, st, r);
+        hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
+        // frame assembly of this range; the second range's offsets continue from the first's
+        if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
+        hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, r, q);
+        if (!half) HIP_TRY(hipEventRecord(c->ev_layout, st));
+        switch (p.channels) {
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64>), dim3(r.fcount), dim3(64), l64, st, r, q); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128>), dim3(r.fcount), dim3(128), l64, st, r, q); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192>), dim3(r.fcount), dim3(192), l64, st, r, q); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256>), dim3(r.fcount), dim3(256), l64, st, r, q); break;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev_join, st1));
+    HIP_TRY(hipStreamWaitEvent(st0, c->ev_join, 0));
+    HIP_TRY(hipGetLastError());
+    c->resid_valid = false;
+    c->last_frames = n_frames;
+    c->last_len = last_len;
+    c->last_params = p;
+    c->packed_valid = true;
+    return FLACGPU_OK;
+}
+
 int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *offsets,
                          uint64_t *total) {
     if (!c || !c->packed_valid) {
@@ -4274,9 +4388,8 @@ int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
     HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, c->own_stream));
-    int rc = flacgpu_analyze_device(c, c->d_in, layout, n_frames, last_len, c->own_stream);
-    if (rc) return rc;
-    rc = flacgpu_pack_device(c, first_frame_number, sample_rate, c->own_stream);
+    int rc = flacgpu_encode_device(c, c->d_in, layout, n_frames, last_len, first_frame_number, sample_rate,
+                                   c->own_stream);
     if (rc) return rc;
     return flacgpu_fetch_frames(c, out, cap, offsets, total);
 }

@@ -78,6 +78,22 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_fetch")
         return plans, subs, res
 
+    def set_two_ranges(self, on):
+        """Cut big batches of 4096-sample frames into two frame ranges on two HIP streams
+        (flacgpu_set_two_ranges); off by default."""
+        rc = _lib.lib().flacgpu_set_two_ranges(self._h, 1 if on else 0)
+        if rc:
+            raise GpuError(rc, "flacgpu_set_two_ranges")
+
+    def encode_device(self, device_ptr, n_frames, last_frame_len, first_frame_number, sample_rate,
+                      layout=LAYOUT_INTERLEAVED, stream=None):
+        """analyze_device + pack_device in one call (see set_two_ranges)."""
+        rc = _lib.lib().flacgpu_encode_device(self._h, C.c_void_p(device_ptr), layout, n_frames,
+                                              last_frame_len, first_frame_number, sample_rate,
+                                              C.c_void_p(stream or 0))
+        if rc:
+            raise GpuError(rc, "flacgpu_encode_device")
+
     def pack_device(self, first_frame_number, sample_rate, stream=None):
         """Device-side frame assembly of the last analysed batch (bytes stay in HBM)."""
         rc = _lib.lib().flacgpu_pack_device(self._h, first_frame_number, sample_rate,

@@ -173,6 +173,20 @@ void *flacgpu_device_buffer(flacgpu_ctx *ctx, int which);
  * Asynchronous; results stay in HBM until flacgpu_fetch_frames. */
 int flacgpu_pack_device(flacgpu_ctx *ctx, uint64_t first_frame_number, uint32_t sample_rate,
                         void *stream);
+/* flacgpu_analyze_device + flacgpu_pack_device of one batch in one asynchronous call: the device
+ * half of `Encoder::encode` for every frame of the batch (encode.rs:2274-2440).
+ * Overlap comes in two forms.  (1) Several contexts on several streams (double / triple buffering
+ * of consecutive batches, what bench.py does): the HBM-, latency- and VALU-bound kernels of
+ * different batches overlap; measured 0.86 -> 0.70 ms per 8192-frame batch with three contexts.
+ * (2) flacgpu_set_two_ranges(ctx, 1): a single batch whose frames all take the 4096-sample wave
+ * kernels is cut into two frame ranges whose kernel chains run on two HIP streams inside the
+ * context (worth ~4 % for a lone batch, counter-productive together with (1), so off by default).
+ * Either way the bytes, plans and counters are those of the two separate calls, and work submitted
+ * to `stream` afterwards sees all of it. */
+int flacgpu_set_two_ranges(flacgpu_ctx *ctx, int on);
+int flacgpu_encode_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                          uint32_t last_frame_len, uint64_t first_frame_number,
+                          uint32_t sample_rate, void *stream);
 /* Copies the packed frames of the last flacgpu_pack_device to the host.  offsets (may be NULL)
  * receives n_frames + 1 byte offsets into `out`; *total (may be NULL) the byte count.  When
  * `out` is NULL or cap is too small only offsets/total are filled and

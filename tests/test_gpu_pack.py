@@ -93,3 +93,37 @@ def test_fast_preset_and_sines():
     run_case(synth_fast(220, 2, 16, 1152 * 5), 2, 16, block_size=1152, max_po=3, max_lpc=0,
              mid_side=False, exhaustive=False)
     run_case(generate_sine_2(8388607.0, 48000.0, 4096 * 3, 441.0, 0.0, 4410.0, 0.1, 1.3), 2, 24)
+
+
+@pytest.mark.parametrize("channels,bps,max_po,max_lpc,exhaustive", [
+    (2, 24, 6, 12, True),     # Options::best
+    (2, 16, 5, 8, False),     # Options::default (fast channel correlation)
+    (2, 16, 5, 0, True),      # FIXED only
+    (1, 24, 6, 12, True),
+    (3, 20, 6, 16, True),
+])
+def test_two_range_pipeline_matches_serial(channels, bps, max_po, max_lpc, exhaustive):
+    """flacgpu_encode_device with flacgpu_set_two_ranges cuts big batches of 4096-sample frames into
+    two frame ranges on two HIP streams: same bytes/offsets as analyze_device + pack_device, and
+    the frames either side of the cut (and the first and last) equal the oracle's."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    n_frames, block, rate, first = 304, 4096, 48000, 70000   # >= 256 frames -> pipelined; odd cut
+    pcm = synth_fast(300 + channels, channels, bps, n_frames * block)
+    an = GpuAnalyzer(block, max_po, max_lpc, True, exhaustive, 2, 0.5, bps, channels, max_frames=n_frames)
+    plans_a, subs_a, _ = an.analyze(pcm, n_frames, block)
+    an.pack_device(first, rate)
+    ser_bytes, ser_off = an.fetch_frames(n_frames)
+    an.set_two_ranges(True)
+    for _ in range(2):   # twice: the second call reuses every buffer
+        pip_bytes, pip_off = an.encode_frames(pcm, n_frames, block, first, rate)
+    plans_b, subs_b, _ = an.fetch(n_frames, want_residuals=False)
+    assert pip_off == ser_off and pip_bytes == ser_bytes
+    assert bytes(plans_a) == bytes(plans_b) and bytes(subs_a) == bytes(subs_b)
+    frames = planar_frames(pcm, channels, block)
+    oopts = orc_options_for(block, max_po, max_lpc, True, exhaustive)
+    cut = ((n_frames // 2) + 15) & ~15
+    for f in (0, cut - 1, cut, cut + 1, n_frames - 1):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, frames[f], frame_number=first + f)
+        assert rc == 0 and pip_bytes[pip_off[f]:pip_off[f + 1]] == fb, f"frame {f}"
+    an.close()
