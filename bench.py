@@ -90,6 +90,9 @@ def main():
     for _ in range(args.contexts - 1):
         ans.append(GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
                                device=local_rank))
+    if len(ans) > 1:
+        for a in ans:   # the SIMDs are kept busy by the other contexts: fewer instructions win
+            a.set_tuning(a.TUNE_LAG_SPLIT, 2)
     streams = [torch.cuda.Stream() for _ in ans]
     step_no = [0]
 

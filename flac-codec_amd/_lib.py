@@ -116,7 +116,7 @@ def lib():
     L.flacgpu_set_timing.argtypes = [vp, C.c_int]
     L.flacgpu_get_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * N_KERNELS)]
     L.flacgpu_pack_device.argtypes = [vp, C.c_uint64, C.c_uint32, vp]
-    L.flacgpu_set_two_ranges.argtypes = [vp, C.c_int]
+    L.flacgpu_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.flacgpu_encode_device.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, vp]
     L.flacgpu_fetch_frames.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]

@@ -87,6 +87,7 @@ struct Params {
     uint32_t n_frames, last_len;
     uint32_t f0, fcount;                           // frames [f0, f0 + fcount) handled by this launch
     uint32_t dbg;                                  // timing experiments only (FLACGPU_DEBUG)
+    uint32_t ac_split;                             // waves the lags of k_autocorr3 are split over (2 or 4)
     // buffers
     const int32_t *planar;
     const double *window_full, *window_last;
@@ -3687,7 +3688,8 @@ struct flacgpu_ctx {
     uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_layout = nullptr;
-    bool two_ranges = false;         // flacgpu_set_two_ranges
+    bool two_ranges = false;         // FLACGPU_TUNE_TWO_RANGES
+    int lag_split = 4;               // FLACGPU_TUNE_LAG_SPLIT
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
     uint64_t packed_cap = 0;        // bytes
@@ -3782,12 +3784,18 @@ size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_
 template <int NL>
 void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                       const double *win, hipStream_t st) {
-    // 4 waves per 64 candidates (lags split 4 ways): the f64 stream needs two waves per SIMD to
-    // issue at full rate, and 8192 frames are only 512 candidate groups (measured 0.23 ms
-    // against 0.31 ms with the lags split 2 ways)
     const uint32_t groups = (nframes * 4 + 63) / 64;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4>), dim3(groups), dim3(256), 0, st, p, frame0,
-                       nframes, n, win);
+    // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
+    // SIMD to issue at full rate and 8192 frames are only 512 candidate groups (0.23 ms against
+    // 0.31 ms split 2 ways).  When other contexts keep the SIMDs busy anyway, the 2-way split wins:
+    // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
+    // instructions).
+    if (p.ac_split == 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2>), dim3(groups), dim3(128), 0, st, p, frame0,
+                           nframes, n, win);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4>), dim3(groups), dim3(256), 0, st, p, frame0,
+                           nframes, n, win);
 }
 // stereo L/R/M/S candidates, <= 24-bit samples, frame length a multiple of 32, order <= 16
 bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
@@ -3957,6 +3965,7 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.last_len = last_len;
     p.f0 = 0;
     p.fcount = n_frames;
+    p.ac_split = (uint32_t)c->lag_split;
     { const char *e = getenv("FLACGPU_DEBUG"); p.dbg = e ? (uint32_t)atoi(e) : 0; }
     p.planar = c->d_planar;
     p.window_full = c->d_window_full;
@@ -4252,13 +4261,20 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     return FLACGPU_OK;
 }
 
-int flacgpu_set_two_ranges(flacgpu_ctx *c, int on) {
+int flacgpu_set_tuning(flacgpu_ctx *c, int key, int value) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
-    c->two_ranges = on != 0;
-    return FLACGPU_OK;
+    switch (key) {
+    case FLACGPU_TUNE_TWO_RANGES: c->two_ranges = value != 0; return FLACGPU_OK;
+    case FLACGPU_TUNE_LAG_SPLIT:
+        if (value != 2 && value != 4) break;
+        c->lag_split = value;
+        return FLACGPU_OK;
+    }
+    g_last_error = "flacgpu_set_tuning: unknown key / value";
+    return FLACGPU_ERR_INVALID_ARG;
 }
 
-// Analysis + frame assembly of one batch in one call.  With flacgpu_set_two_ranges(ctx, 1), when
+// Analysis + frame assembly of one batch in one call.  With FLACGPU_TUNE_TWO_RANGES set, when
 // every frame takes the wave kernels (4096-sample blocks, order <= 16, <= 4 channels), the batch
 // is cut into two frame ranges that run
 // the whole kernel chain on two HIP streams: the HBM-bound (K0, copy-out), latency-bound (Levinson,

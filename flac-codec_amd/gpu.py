@@ -78,12 +78,17 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_fetch")
         return plans, subs, res
 
+    TUNE_TWO_RANGES, TUNE_LAG_SPLIT = 1, 2
+
+    def set_tuning(self, key, value):
+        rc = _lib.lib().flacgpu_set_tuning(self._h, key, value)
+        if rc:
+            raise GpuError(rc, "flacgpu_set_tuning")
+
     def set_two_ranges(self, on):
         """Cut big batches of 4096-sample frames into two frame ranges on two HIP streams
-        (flacgpu_set_two_ranges); off by default."""
-        rc = _lib.lib().flacgpu_set_two_ranges(self._h, 1 if on else 0)
-        if rc:
-            raise GpuError(rc, "flacgpu_set_two_ranges")
+        (FLACGPU_TUNE_TWO_RANGES); off by default."""
+        self.set_tuning(self.TUNE_TWO_RANGES, 1 if on else 0)
 
     def encode_device(self, device_ptr, n_frames, last_frame_len, first_frame_number, sample_rate,
                       layout=LAYOUT_INTERLEAVED, stream=None):

@@ -178,12 +178,19 @@ int flacgpu_pack_device(flacgpu_ctx *ctx, uint64_t first_frame_number, uint32_t 
  * Overlap comes in two forms.  (1) Several contexts on several streams (double / triple buffering
  * of consecutive batches, what bench.py does): the HBM-, latency- and VALU-bound kernels of
  * different batches overlap; measured 0.86 -> 0.70 ms per 8192-frame batch with three contexts.
- * (2) flacgpu_set_two_ranges(ctx, 1): a single batch whose frames all take the 4096-sample wave
- * kernels is cut into two frame ranges whose kernel chains run on two HIP streams inside the
- * context (worth ~4 % for a lone batch, counter-productive together with (1), so off by default).
+ * (2) FLACGPU_TUNE_TWO_RANGES: a single batch whose frames all take the 4096-sample wave kernels is
+ * cut into two frame ranges whose kernel chains run on two HIP streams inside the context (worth
+ * ~4 % for a lone batch, counter-productive together with (1), so off by default).
  * Either way the bytes, plans and counters are those of the two separate calls, and work submitted
  * to `stream` afterwards sees all of it. */
-int flacgpu_set_two_ranges(flacgpu_ctx *ctx, int on);
+enum {
+    FLACGPU_TUNE_TWO_RANGES = 1, /* 0 (default) / 1 */
+    /* waves the autocorrelation lags of a 64-candidate group are split over: 4 (default; best for
+     * a context that has the GPU to itself) or 2 (fewer instructions; best when several contexts
+     * keep the SIMDs busy).  Results are identical. */
+    FLACGPU_TUNE_LAG_SPLIT = 2
+};
+int flacgpu_set_tuning(flacgpu_ctx *ctx, int key, int value);
 int flacgpu_encode_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,
                           uint32_t last_frame_len, uint64_t first_frame_number,
                           uint32_t sample_rate, void *stream);

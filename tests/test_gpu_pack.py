@@ -103,7 +103,7 @@ def test_fast_preset_and_sines():
     (3, 20, 6, 16, True),
 ])
 def test_two_range_pipeline_matches_serial(channels, bps, max_po, max_lpc, exhaustive):
-    """flacgpu_encode_device with flacgpu_set_two_ranges cuts big batches of 4096-sample frames into
+    """flacgpu_encode_device with FLACGPU_TUNE_TWO_RANGES cuts big batches of 4096-sample frames into
     two frame ranges on two HIP streams: same bytes/offsets as analyze_device + pack_device, and
     the frames either side of the cut (and the first and last) equal the oracle's."""
     from flac_codec_amd.gpu import GpuAnalyzer
@@ -115,6 +115,7 @@ def test_two_range_pipeline_matches_serial(channels, bps, max_po, max_lpc, exhau
     an.pack_device(first, rate)
     ser_bytes, ser_off = an.fetch_frames(n_frames)
     an.set_two_ranges(True)
+    an.set_tuning(an.TUNE_LAG_SPLIT, 2)   # autocorrelation lags over 2 waves instead of 4: same sums
     for _ in range(2):   # twice: the second call reuses every buffer
         pip_bytes, pip_off = an.encode_frames(pcm, n_frames, block, first, rate)
     plans_b, subs_b, _ = an.fetch(n_frames, want_residuals=False)
