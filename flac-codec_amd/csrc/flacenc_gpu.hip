@@ -1933,30 +1933,33 @@ __device__ __forceinline__ uint32_t rice_folded(Src &src, int e, uint32_t first)
         return (uint32_t)(r ^ (r >> 31));
     }
 }
+// leaf_sum: for a generated source, this lane's sum |r| (the order statistics already have it:
+// the first pass is skipped); ignored for a stored source.
 template <int MAXORD, class Src>
-__device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Params &p) {
+__device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Params &p,
+                                              uint64_t leaf_sum = 0) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t P = rice_levels(FN, p);
     const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
     const uint32_t first = lane == 0 ? order : 0u;
-    uint64_t sum_t = 0;
+    uint64_t sum_t = leaf_sum;
     uint32_t neg = 0;
-    src.reset();
+    if constexpr (Src::STORED) {
+        sum_t = 0;
 #pragma unroll
-    for (int e = 0; e < 64; e += 2) {
-        int32_t r0 = src.resid(e), r1 = src.resid(e + 1);
-        if (e < MAXORD) r0 = (uint32_t)e >= first ? r0 : 0;
-        if (e + 1 < MAXORD) r1 = (uint32_t)(e + 1) >= first ? r1 : 0;
-        const int32_t s0 = r0 >> 31, s1 = r1 >> 31;
-        const uint32_t t0 = (uint32_t)(r0 ^ s0), t1 = (uint32_t)(r1 ^ s1);
-        if constexpr (Src::STORED) {
+        for (int e = 0; e < 64; e += 2) {
+            int32_t r0 = src.resid(e), r1 = src.resid(e + 1);
+            if (e < MAXORD) r0 = (uint32_t)e >= first ? r0 : 0;
+            if (e + 1 < MAXORD) r1 = (uint32_t)(e + 1) >= first ? r1 : 0;
+            const int32_t s0 = r0 >> 31, s1 = r1 >> 31;
+            const uint32_t t0 = (uint32_t)(r0 ^ s0), t1 = (uint32_t)(r1 ^ s1);
             src.a[e] = (int32_t)t0;
             src.a[e + 1] = (int32_t)t1;
+            neg -= (uint32_t)s0;
+            neg -= (uint32_t)s1;
+            sum_t += t0 + t1;  // each < 2^31
+            if ((e & 7) == 6) __builtin_amdgcn_sched_barrier(0);
         }
-        neg -= (uint32_t)s0;
-        neg -= (uint32_t)s1;
-        sum_t += t0 + t1;  // each < 2^31
-        if ((e & 7) == 6) __builtin_amdgcn_sched_barrier(0);
     }
     const uint64_t mysum = sum_t + neg;  // sum |r| of this lane's 64 samples, < 2^37
     // inclusive prefix of the leaf sums in two limbs
@@ -2041,15 +2044,27 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
         const uint32_t msrc = (1u << bp) + (lane >> (6 - bp));
         const uint32_t mrec = bp == 6 ? lrec : (uint32_t)__shfl(irec, (int)(msrc & 63), 64);
         const uint32_t k = (mrec >> 18) & 0xFF;
-        const uint32_t sh = (k == 0 || k == 0xFF) ? 0u : k - 1u;
         uint32_t q = 0;
-        src.reset();
+        if constexpr (Src::STORED) {
+            const uint32_t sh = (k == 0 || k == 0xFF) ? 0u : k - 1u;
 #pragma unroll
-        for (int e = 0; e < 64; e++) {
-            q += rice_folded<MAXORD>(src, e, first) >> sh;
-            if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int e = 0; e < 64; e++) {
+                q += (uint32_t)src.a[e] >> sh;
+                if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            mine += k == 0xFF ? 0u : k == 0 ? 2u * (uint32_t)sum_t + neg : q;
+        } else {  // regenerate the residual: zigzag(r) >> k directly (k = 0 included)
+            const uint32_t ks = k == 0xFF ? 0u : k;
+            src.reset();
+#pragma unroll
+            for (int e = 0; e < 64; e++) {
+                int32_t r = src.resid(e);
+                if (e < MAXORD) r = (uint32_t)e >= first ? r : 0;
+                q += zigzag(r) >> ks;
+                if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            mine += k == 0xFF ? 0u : q;
         }
-        mine += k == 0xFF ? 0u : k == 0 ? 2u * (uint32_t)sum_t + neg : q;
     } else {
         if (lane == 0) {
             w.price = 0xFF;
@@ -2195,7 +2210,8 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     // Values are biased by 2^30 (unsigned), |a - b| + acc is one v_sad_u32; u32 partial sums are
     // flushed every 8 terms (|d4| < 2^28 for <= 25-bit candidates).
     constexpr uint32_t BIAS = 1u << 30;
-    uint64_t sm[5] = {0, 0, 0, 0, 0};
+    uint64_t sm[5] = {0, 0, 0, 0, 0}, leaf[5];
+    uint32_t w1 = 0, w2 = 0, w3 = 0;
     {
         const uint32_t hb0 = (uint32_t)h[0] + BIAS, hb1 = (uint32_t)h[1] + BIAS, hb2 = (uint32_t)h[2] + BIAS,
                        hb3 = (uint32_t)h[3] + BIAS;
@@ -2214,6 +2230,9 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
             a3 = __usad(d2, p2, a3);
             a4 = __usad(d3, p3, a4);
             p0 = xb; p1 = d1; p2 = d2; p3 = d3;
+            if (e == 0) w1 = a1;   // order K's warm-up = samples 0..K-1: sum |d_K| over them
+            if (e == 1) w2 = a2;
+            if (e == 2) w3 = a3;
             if (e == 3) { c0 = a0; c1 = a1; c2 = a2; c3 = a3; c4 = a4; }
             if ((e & 7) == 7) {
                 sm[0] += a0; sm[1] += a1; sm[2] += a2; sm[3] += a3; sm[4] += a4;
@@ -2221,7 +2240,15 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
                 __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 64 chains
             }
         }
-        if (lane == 0) { sm[0] -= c0; sm[1] -= c1; sm[2] -= c2; sm[3] -= c3; sm[4] -= c4; }
+        // sm: this lane's sum |d_K| over all 64 samples = the Rice search's leaf sums once the
+        // warm-up of the chosen order is taken out (lane 0); the order choice sums [4, n)
+        if (lane == 0) {
+            leaf[0] = sm[0]; leaf[1] = sm[1] - w1; leaf[2] = sm[2] - w2; leaf[3] = sm[3] - w3; leaf[4] = sm[4] - c4;
+            sm[0] -= c0; sm[1] -= c1; sm[2] -= c2; sm[3] -= c3; sm[4] -= c4;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) leaf[k] = sm[k];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) sm[k] = wave_total_u48(sm[k]);
@@ -2231,11 +2258,11 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
         if (sm[k] < sm[forder]) forder = k;  // min_by_key: first minimum wins
     WaveRice fw;
     switch (forder) {
-    case 0: fw = wave_rice<4>(FixedSrc<0>{x, h}, 0, p); break;
-    case 1: fw = wave_rice<4>(FixedSrc<1>{x, h}, 1, p); break;
-    case 2: fw = wave_rice<4>(FixedSrc<2>{x, h}, 2, p); break;
-    case 3: fw = wave_rice<4>(FixedSrc<3>{x, h}, 3, p); break;
-    default: fw = wave_rice<4>(FixedSrc<4>{x, h}, 4, p); break;
+    case 0: fw = wave_rice<4>(FixedSrc<0>{x, h}, 0, p, leaf[0]); break;
+    case 1: fw = wave_rice<4>(FixedSrc<1>{x, h}, 1, p, leaf[1]); break;
+    case 2: fw = wave_rice<4>(FixedSrc<2>{x, h}, 2, p, leaf[2]); break;
+    case 3: fw = wave_rice<4>(FixedSrc<3>{x, h}, 3, p, leaf[3]); break;
+    default: fw = wave_rice<4>(FixedSrc<4>{x, h}, 4, p, leaf[4]); break;
     }
     const uint32_t fixed_bits = 8u + wasted + forder * bps_eff + fw.bits;
     const bool fixed_ok = fw.ok;
