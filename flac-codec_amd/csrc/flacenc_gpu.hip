@@ -1882,26 +1882,27 @@ __device__ __forceinline__ uint32_t sread(uint32_t v, int lane) {
 // Residual sources of wave_rice.  resid(e) is called with e = 0..63 ascending after reset().
 // StoredSrc: residuals held in a register array (the LPC residual, computed in place over the
 // samples); they are folded in place by the first pass.
+template <int SPL>
 struct StoredSrc {
     static constexpr bool STORED = true;
-    int32_t (&a)[64];
+    int32_t (&a)[SPL];
     __device__ __forceinline__ void reset() {}
     __device__ __forceinline__ int32_t resid(int e) { return a[e]; }
 };
 // FixedSrc<K>: residual of fixed order K generated on the fly from the samples (encode.rs:
 // 3039-3060); nothing is stored, the second pass of the search simply regenerates it (K
 // subtractions per sample) -- this keeps the kernel at 64 instead of 128 array registers.
-template <int K>
+template <int K, int SPL>
 struct FixedSrc {
     static constexpr bool STORED = false;
-    int32_t (&x)[64];
+    int32_t (&x)[SPL];
     int32_t (&h)[4];  // the 4 samples before x[0]
     int32_t q0, q1, q2, q3;
     __device__ __forceinline__ void reset() {
         // make the samples opaque: otherwise the compiler shares this pass's differences with
         // the previous pass (and with the order statistics), i.e. keeps 64..256 of them live
 #pragma unroll
-        for (int e = 0; e < 64; e++) asm volatile("" : "+v"(x[e]));
+        for (int e = 0; e < SPL; e++) asm volatile("" : "+v"(x[e]));
 #pragma unroll
         for (int k = 0; k < 4; k++) asm volatile("" : "+v"(h[k]));
         q0 = h[3];
@@ -1916,14 +1917,15 @@ struct FixedSrc {
     }
 };
 
-// Rice search of one wave's residual (encode.rs:3862-3947), lane l = samples [64 l, 64 l + 64).
+// Rice search of one wave's residual (encode.rs:3862-3947), lane l = samples [SPL l, SPL l + SPL)
+// of a block of 64 SPL samples (SPL >= 16: one finest partition of a partition-order-6 block).
 // Warm-up entries (lane 0, e < order <= MAXORD) count as zero and every value is folded to
 // t = r ^ (r >> 31) = zigzag(r) >> 1, so that
 //   sum |r| = sum t + #negative,  zigzag(r) >> k = t >> (k - 1) for k >= 1,
 //   sum zigzag(r) = 2 sum t + #negative.
 // Level totals come from one DPP scan of the node estimates plus ballots; nothing touches LDS.
 // folded value of sample e in the second and later passes
-template <int MAXORD, class Src>
+template <int SPL, int MAXORD, class Src>
 __device__ __forceinline__ uint32_t rice_folded(Src &src, int e, uint32_t first) {
     if constexpr (Src::STORED) {
         return (uint32_t)src.a[e];
@@ -1935,11 +1937,12 @@ __device__ __forceinline__ uint32_t rice_folded(Src &src, int e, uint32_t first)
 }
 // leaf_sum: for a generated source, this lane's sum |r| (the order statistics already have it:
 // the first pass is skipped); ignored for a stored source.
-template <int MAXORD, class Src>
+template <int SPL, int MAXORD, class Src>
 __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Params &p,
                                               uint64_t leaf_sum = 0) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t P = rice_levels(FN, p);
+    constexpr uint32_t N = 64u * SPL;  // block length
+    const uint32_t P = rice_levels(N, p);
     const uint32_t rice_max = p.use_rice2 ? 31u : 15u;
     const uint32_t first = lane == 0 ? order : 0u;
     uint64_t sum_t = leaf_sum;
@@ -1947,7 +1950,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
     if constexpr (Src::STORED) {
         sum_t = 0;
 #pragma unroll
-        for (int e = 0; e < 64; e += 2) {
+        for (int e = 0; e < SPL; e += 2) {
             int32_t r0 = src.resid(e), r1 = src.resid(e + 1);
             if (e < MAXORD) r0 = (uint32_t)e >= first ? r0 : 0;
             if (e + 1 < MAXORD) r1 = (uint32_t)(e + 1) >= first ? r1 : 0;
@@ -1967,7 +1970,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
     const uint32_t sc_hi = wave_scan_u32((uint32_t)(mysum >> 20));
     const uint64_t incl = ((uint64_t)sc_hi << 20) + sc_lo;
     // leaf node 64 + lane (level 6) and internal node `lane` (levels 0..5), heap numbering
-    const uint32_t leaf_cnt = 64u - first;
+    const uint32_t leaf_cnt = (uint32_t)SPL - first;
     const PartEval le = partition_eval(leaf_cnt, mysum, rice_max);
     const uint32_t node = lane;
     const uint32_t lvl = node ? 31u - (uint32_t)__builtin_clz(node) : 0u;
@@ -1977,7 +1980,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
     const uint64_t top = __shfl(incl, (int)(hi & 63), 64);
     const uint64_t bot = __shfl(incl, (int)((lo ? lo - 1 : 0) & 63), 64);
     const uint64_t isum = top - (lo ? bot : 0ull);
-    const uint32_t plen = FN >> lvl;
+    const uint32_t plen = N >> lvl;
     const uint32_t istart = j * plen, iend = istart + plen;
     const uint32_t icnt = (node && iend > order) ? iend - (istart > order ? istart : order) : 0u;
     const PartEval ie = partition_eval(icnt, isum, rice_max);
@@ -2048,7 +2051,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
         if constexpr (Src::STORED) {
             const uint32_t sh = (k == 0 || k == 0xFF) ? 0u : k - 1u;
 #pragma unroll
-            for (int e = 0; e < 64; e++) {
+            for (int e = 0; e < SPL; e++) {
                 q += (uint32_t)src.a[e] >> sh;
                 if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
@@ -2057,7 +2060,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
             const uint32_t ks = k == 0xFF ? 0u : k;
             src.reset();
 #pragma unroll
-            for (int e = 0; e < 64; e++) {
+            for (int e = 0; e < SPL; e++) {
                 int32_t r = src.resid(e);
                 if (e < MAXORD) r = (uint32_t)e >= first ? r : 0;
                 q += zigzag(r) >> ks;
@@ -2069,12 +2072,12 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
         if (lane == 0) {
             w.price = 0xFF;
             w.pesc = 31;  // one escaped 31-bit partition, encode.rs:3887-3895
-            mine += 4u + 5u + 31u * (FN - order);
+            mine += 4u + 5u + 31u * (N - order);
         }
         // t >= 2^30  <=>  r outside [-2^30, 2^30): write_signed_counted(31) fails (:3857)
         src.reset();
 #pragma unroll
-        for (int e = 0; e < 64; e++) wide |= rice_folded<MAXORD>(src, e, first) >= (1u << 30);
+        for (int e = 0; e < SPL; e++) wide |= rice_folded<SPL, MAXORD>(src, e, first) >= (1u << 30);
     }
     w.bits = 6u + wave_total_u32(mine);  // method (2) + partition order (4), :3949, :3902
     w.ok = !__any(wide);
@@ -2090,8 +2093,8 @@ struct KeepResidual {  // fir64 consumer: just store the residual
 };
 // f(e, residual) -> value stored in x[e]: lets a caller consume each residual where it is
 // produced (k_frame64 sums the code lengths there)
-template <int T, int CBASE = 2, class F = KeepResidual>
-__device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[16], uint32_t lpw,
+template <int T, int SPL, int CBASE = 2, class F = KeepResidual>
+__device__ __forceinline__ uint32_t fir64(int32_t (&x)[SPL], const int32_t (&hp)[16], uint32_t lpw,
                                           uint32_t order, uint32_t shift, F &&f = F()) {
     int32_t c[T];  // wave-uniform (SGPRs): coefficient j was loaded by lane CBASE + j
 #pragma unroll
@@ -2100,7 +2103,7 @@ __device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[
     const uint32_t warm = (threadIdx.x & 63) == 0 ? ((1u << order) - 1u) : 0u;
     uint32_t ovf = 0;
 #pragma unroll
-    for (int e = 63; e >= 0; e--) {
+    for (int e = SPL - 1; e >= 0; e--) {
         long long sum = 0;
 #pragma unroll
         for (int j = 0; j < T; j++) {
@@ -2122,7 +2125,8 @@ __device__ __forceinline__ uint32_t fir64(int32_t (&x)[64], const int32_t (&hp)[
 __device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uint32_t wasted,
                                                 uint32_t bps, uint32_t order, uint32_t precision,
                                                 uint32_t shift, uint32_t source, uint32_t bits,
-                                                const WaveRice *w, uint32_t coeff /* of `lane` */) {
+                                                const WaveRice *w, uint32_t coeff /* of `lane` */,
+                                                uint32_t N) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *d = reinterpret_cast<uint32_t *>(dst);
     if (lane == 0) {
@@ -2133,7 +2137,7 @@ __device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uin
         d[1] = precision | (shift << 8) | (method << 16) | (porder << 24);
         d[2] = source;                                       // source, reserved[3]
         d[3] = count;                                        // n_partitions
-        d[4] = w ? (w->bp >= 0 ? FN >> w->bp : FN) : 0u;     // part_len
+        d[4] = w ? (w->bp >= 0 ? N >> w->bp : N) : 0u;       // part_len
         d[5] = bits;
     }
     if (lane < 32) d[6 + lane] = lane < order ? coeff : 0u;  // coeffs
@@ -2143,7 +2147,31 @@ __device__ __forceinline__ void store_plan_wave(SubPlan *dst, uint32_t type, uin
     b[24 + 128 + 64 + lane] = live ? w->pesc : 0;    // escape_bits[lane]
 }
 
+// this lane's SPL consecutive samples of a row (16-byte loads when SPL is a multiple of 4,
+// 8-byte loads otherwise: a lane starts SPL * 4 bytes after its neighbour)
+template <int SPL>
+__device__ __forceinline__ void load_lane(const int32_t *row, uint32_t lane, int32_t (&v)[SPL]) {
+    if constexpr (SPL % 4 == 0) {
+        const int4 *pp = reinterpret_cast<const int4 *>(row) + (SPL / 4) * lane;
+#pragma unroll
+        for (int q = 0; q < SPL / 4; q++) {
+            const int4 a = pp[q];
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
+    } else {
+        static_assert(SPL % 2 == 0, "samples per lane must be even");
+        const int2 *pp = reinterpret_cast<const int2 *>(row) + (SPL / 2) * lane;
+#pragma unroll
+        for (int q = 0; q < SPL / 2; q++) {
+            const int2 a = pp[q];
+            v[2 * q] = a.x; v[2 * q + 1] = a.y;
+        }
+    }
+}
+
+template <int SPL>
 __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
+    constexpr uint32_t N = 64u * SPL;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t local = blockIdx.x * 4 + wave;
@@ -2161,38 +2189,21 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     const uint32_t lpw = (want_lpc && lane < 34) ? lpw_p[lane] : 1u;       // status 1 = no LPC
     const uint32_t qv = (want_lpc && lane < 32) ? lpw_p[2 + lane] : 0u;     // coefficient `lane`
     const CandSrc src = cand_src(p, frame, cand);
-    int32_t x[64];
-    {
-        const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 16 * lane;
-        const int4 *pb = reinterpret_cast<const int4 *>(src.b) + 16 * lane;
-        if (src.mode == 0) {
+    int32_t x[SPL];
+    load_lane<SPL>(src.a, lane, x);
+    if (src.mode) {  // mid = (l + r) >> 1 (the shift joins the wasted-bits shift), side = l - r
+        int32_t xb[SPL];
+        load_lane<SPL>(src.b, lane, xb);
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int4 a = pa[q];
-                x[4 * q] = a.x; x[4 * q + 1] = a.y; x[4 * q + 2] = a.z; x[4 * q + 3] = a.w;
-            }
-        } else if (src.mode == 1) {  // mid = (l + r) >> 1: the shift joins the wasted-bits shift
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int4 a = pa[q], b = pb[q];
-                x[4 * q] = (int32_t)((uint32_t)a.x + (uint32_t)b.x); x[4 * q + 1] = (int32_t)((uint32_t)a.y + (uint32_t)b.y);
-                x[4 * q + 2] = (int32_t)((uint32_t)a.z + (uint32_t)b.z); x[4 * q + 3] = (int32_t)((uint32_t)a.w + (uint32_t)b.w);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int4 a = pa[q], b = pb[q];
-                x[4 * q] = combine(2, a.x, b.x); x[4 * q + 1] = combine(2, a.y, b.y);
-                x[4 * q + 2] = combine(2, a.z, b.z); x[4 * q + 3] = combine(2, a.w, b.w);
-            }
-        }
+        for (int e = 0; e < SPL; e++)
+            x[e] = src.mode == 1 ? (int32_t)((uint32_t)x[e] + (uint32_t)xb[e]) : combine(2, x[e], xb[e]);
     }
     CandInfo ci;
     memcpy(&ci, &ci_raw, 4);
     if (!ci.active) return;
     SubPlan *out = p.cand_plan + cidx;
     if (ci.is_const) {  // all zero -> CONSTANT(0) at the candidate's bps (encode.rs:2883-2887)
-        store_plan_wave(out, FLACGPU_SUB_CONSTANT, 0, src.bps, 0, 0, 0, src.source, 8u + src.bps, nullptr, 0);
+        store_plan_wave(out, FLACGPU_SUB_CONSTANT, 0, src.bps, 0, 0, 0, src.source, 8u + src.bps, nullptr, 0, N);
         return;
     }
     const uint32_t wasted = __builtin_amdgcn_readfirstlane((uint32_t)ci.wasted);
@@ -2200,12 +2211,12 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     {
         const uint32_t sh = wasted + (src.mode == 1 ? 1u : 0u);
 #pragma unroll
-        for (int e = 0; e < 64; e++) x[e] >>= sh;
+        for (int e = 0; e < SPL; e++) x[e] >>= sh;
     }
     // the previous lane's last 4 samples (zeros before the block start)
     int32_t h[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = lane_prev(x[60 + k]);
+    for (int k = 0; k < 4; k++) h[k] = lane_prev(x[SPL - 4 + k]);
     // ---- FIXED: abs sums of the iterated differences over [4, n) (encode.rs:3039-3073).
     // Values are biased by 2^30 (unsigned), |a - b| + acc is one v_sad_u32; u32 partial sums are
     // flushed every 8 terms (|d4| < 2^28 for <= 25-bit candidates).
@@ -2221,7 +2232,7 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;  // contributions of samples 0..3
 #pragma unroll
-        for (int e = 0; e < 64; e++) {
+        for (int e = 0; e < SPL; e++) {
             const uint32_t xb = (uint32_t)x[e] + BIAS;
             const uint32_t d1 = xb - p0 + BIAS, d2 = d1 - p1 + BIAS, d3 = d2 - p2 + BIAS;
             a0 = __usad(xb, BIAS, a0);
@@ -2234,7 +2245,7 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
             if (e == 1) w2 = a2;
             if (e == 2) w3 = a3;
             if (e == 3) { c0 = a0; c1 = a1; c2 = a2; c3 = a3; c4 = a4; }
-            if ((e & 7) == 7) {
+            if ((e & 7) == 7 || e == SPL - 1) {
                 sm[0] += a0; sm[1] += a1; sm[2] += a2; sm[3] += a3; sm[4] += a4;
                 a0 = a1 = a2 = a3 = a4 = 0;
                 __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting all 64 chains
@@ -2258,11 +2269,11 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
         if (sm[k] < sm[forder]) forder = k;  // min_by_key: first minimum wins
     WaveRice fw;
     switch (forder) {
-    case 0: fw = wave_rice<4>(FixedSrc<0>{x, h}, 0, p, leaf[0]); break;
-    case 1: fw = wave_rice<4>(FixedSrc<1>{x, h}, 1, p, leaf[1]); break;
-    case 2: fw = wave_rice<4>(FixedSrc<2>{x, h}, 2, p, leaf[2]); break;
-    case 3: fw = wave_rice<4>(FixedSrc<3>{x, h}, 3, p, leaf[3]); break;
-    default: fw = wave_rice<4>(FixedSrc<4>{x, h}, 4, p, leaf[4]); break;
+    case 0: fw = wave_rice<SPL, 4>(FixedSrc<0, SPL>{x, h}, 0, p, leaf[0]); break;
+    case 1: fw = wave_rice<SPL, 4>(FixedSrc<1, SPL>{x, h}, 1, p, leaf[1]); break;
+    case 2: fw = wave_rice<SPL, 4>(FixedSrc<2, SPL>{x, h}, 2, p, leaf[2]); break;
+    case 3: fw = wave_rice<SPL, 4>(FixedSrc<3, SPL>{x, h}, 3, p, leaf[3]); break;
+    default: fw = wave_rice<SPL, 4>(FixedSrc<4, SPL>{x, h}, 4, p, leaf[4]); break;
     }
     const uint32_t fixed_bits = 8u + wasted + forder * bps_eff + fw.bits;
     const bool fixed_ok = fw.ok;
@@ -2277,18 +2288,18 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
         lorder = lmeta & 0xFF;
         int32_t hp[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) hp[k] = lane_prev(x[48 + k]);
+        for (int k = 0; k < 16; k++) hp[k] = lane_prev(x[SPL - 16 + k]);
         uint32_t ovf;
         switch ((lorder + 3) >> 2) {
-        case 1: ovf = fir64<4>(x, hp, lpw, lorder, lshift); break;
-        case 2: ovf = fir64<8>(x, hp, lpw, lorder, lshift); break;
-        case 3: ovf = fir64<12>(x, hp, lpw, lorder, lshift); break;
-        default: ovf = fir64<16>(x, hp, lpw, lorder, lshift); break;
+        case 1: ovf = fir64<4, SPL>(x, hp, lpw, lorder, lshift); break;
+        case 2: ovf = fir64<8, SPL>(x, hp, lpw, lorder, lshift); break;
+        case 3: ovf = fir64<12, SPL>(x, hp, lpw, lorder, lshift); break;
+        default: ovf = fir64<16, SPL>(x, hp, lpw, lorder, lshift); break;
         }
         if (__any(ovf)) {
             if (lane == 0) atomicAdd(&p.stats[0], 1u);
         } else {
-            lw = wave_rice<16>(StoredSrc{x}, lorder, p);
+            lw = wave_rice<SPL, 16>(StoredSrc<SPL>{x}, lorder, p);
             lpc_ok = lw.ok;
             if (!lpc_ok && lane == 0) atomicAdd(&p.stats[0], 1u);
             lpc_bits = 8u + wasted + lorder * bps_eff + 4u + 5u + lorder * lprec + lw.bits;
@@ -2298,16 +2309,16 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     // (Err,Err) -> VERBATIM; then the verbatim threshold (encode.rs:2929-2979)
     const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);
     const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
-    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < FN * bps_eff);
+    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < N * bps_eff);
     if (verbatim)
         store_plan_wave(out, FLACGPU_SUB_VERBATIM, wasted, bps_eff, 0, 0, 0, src.source,
-                        8u + wasted + FN * bps_eff, nullptr, 0);
+                        8u + wasted + N * bps_eff, nullptr, 0, N);
     else if (use_lpc)
         store_plan_wave(out, FLACGPU_SUB_LPC, wasted, bps_eff, lorder, lprec, lshift, src.source, lpc_bits,
-                        &lw, qv);
+                        &lw, qv, N);
     else
         store_plan_wave(out, FLACGPU_SUB_FIXED, wasted, bps_eff, forder, 0, 0, src.source, fixed_bits,
-                        &fw, 0);
+                        &fw, 0, N);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2940,8 +2951,8 @@ __constant__ __attribute__((aligned(16))) CrcTables kCrcT = CrcTables();
 
 // words of LDS a whole frame of 4096-sample subframes may need (VERBATIM everywhere + header +
 // CRC-16 + one guard word for the funnel shifts); multiple of 4 words
-__host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps) {
-    return (((16u + 2u) * 8u + channels * (FN * (bps + 1u) + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
+__host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps, uint32_t n = FN) {
+    return (((16u + 2u) * 8u + channels * (n * (bps + 1u) + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -3070,6 +3081,7 @@ struct BitRun {  // a lane's contiguous MSB-first bit run inside an LDS word arr
     }
 };
 
+template <int SPL>
 __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, uint32_t ch,
                                               uint32_t *sb, uint32_t base) {
     const uint32_t lane = threadIdx.x & 63;
@@ -3089,45 +3101,31 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         rowa = p.planar + ((size_t)frame * p.channels + ch) * p.ldb;  // source == ch
         rowb = rowa;
     }
-    int32_t x[64];
+    int32_t x[SPL];
+    load_lane<SPL>(rowa, lane, x);
     if (p.stereo4) {
-        int4 a[16], b[16];
-        const int4 *pa = reinterpret_cast<const int4 *>(rowa) + 16 * lane;
-        const int4 *pb = reinterpret_cast<const int4 *>(rowb) + 16 * lane;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            a[q] = pa[q];
-            b[q] = pb[q];
-        }
+        int32_t xb[SPL];
+        load_lane<SPL>(rowb, lane, xb);
         const uint32_t srcid = sread(pw, 2) & 0xFF;
         // L: a, R: b, mid: a + b (>> 1 below), side: a - b
         const int32_t ca = srcid == 1 ? 0 : 1;
         const int32_t cb = srcid == 0 ? 0 : srcid == FLACGPU_SRC_SIDE ? -1 : 1;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            x[4 * q] = a[q].x * ca + b[q].x * cb; x[4 * q + 1] = a[q].y * ca + b[q].y * cb;
-            x[4 * q + 2] = a[q].z * ca + b[q].z * cb; x[4 * q + 3] = a[q].w * ca + b[q].w * cb;
-        }
-    } else {
-        const int4 *pa = reinterpret_cast<const int4 *>(rowa) + 16 * lane;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int4 a = pa[q];
-            x[4 * q] = a.x; x[4 * q + 1] = a.y; x[4 * q + 2] = a.z; x[4 * q + 3] = a.w;
-        }
+        for (int e = 0; e < SPL; e++) x[e] = x[e] * ca + xb[e] * cb;
     }
-    const uint32_t d0 = sread(pw, 0), d1 = sread(pw, 1), d2 = sread(pw, 2), plen = sread(pw, 4);
+    const uint32_t d0 = sread(pw, 0), d1 = sread(pw, 1), d2 = sread(pw, 2);
     const uint32_t type = d0 & 0xFF, wasted = (d0 >> 8) & 0xFF, bps = (d0 >> 16) & 0xFF, order = d0 >> 24;
     const uint32_t prec = d1 & 0xFF, shift = (d1 >> 8) & 0xFF, method = (d1 >> 16) & 0xFF, porder = d1 >> 24;
     {
         const uint32_t sh = wasted + ((p.stereo4 && (d2 & 0xFF) == FLACGPU_SRC_MID) ? 1u : 0u);
 #pragma unroll
-        for (int e = 0; e < 64; e++) x[e] >>= sh;
+        for (int e = 0; e < SPL; e++) x[e] >>= sh;
     }
-    // Rice parameters of the partition this lane's 64 samples lie in (partitions are >= 64 long):
+    // Rice parameters of the partition this lane's samples lie in (a partition is 2^(6 - porder)
+    // lanes; the warm-up never swallows a whole partition since order <= 16 <= SPL):
     // rice[pj] is byte pj of dwords 38..53, escape_bits[pj] byte pj of dwords 54..69
-    const uint32_t lg = plen ? 31u - (uint32_t)__builtin_clz(plen) : 12u;
-    const uint32_t pj = (64u * lane) >> lg;
+    const uint32_t lpp = 6u - (porder < 6u ? porder : 6u);  // log2(lanes per partition)
+    const uint32_t pj = lane >> lpp;
     const bool coded = type == FLACGPU_SUB_FIXED || type == FLACGPU_SUB_LPC;
     const uint32_t rw = __shfl(pw, (int)(38 + (pj >> 2)), 64);
     const uint32_t ei = 54 + (pj >> 2);
@@ -3152,9 +3150,9 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     if (type == FLACGPU_SUB_CONSTANT) return;
     BitRun br;
     if (type == FLACGPU_SUB_VERBATIM) {
-        br.init(sb, body0 + lane * 64u * bps);
+        br.init(sb, body0 + lane * (uint32_t)SPL * bps);
 #pragma unroll
-        for (int e = 0; e < 64; e++) br.put((uint32_t)x[e] & smask, bps);
+        for (int e = 0; e < SPL; e++) br.put((uint32_t)x[e] & smask, bps);
         br.finish();
         return;
     }
@@ -3190,24 +3188,24 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         resid_pos += 9 + order * prec;
         int32_t hp[16];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) hp[kk] = lane_prev(x[48 + kk]);
+        for (int kk = 0; kk < 16; kk++) hp[kk] = lane_prev(x[SPL - 16 + kk]);
         switch ((order + 3) >> 2) {  // the residual, in place (encode.rs:3181-3197)
-        case 1: fir64<4, 6>(x, hp, cw, order, shift, len); break;
-        case 2: fir64<8, 6>(x, hp, cw, order, shift, len); break;
-        case 3: fir64<12, 6>(x, hp, cw, order, shift, len); break;
-        default: fir64<16, 6>(x, hp, cw, order, shift, len); break;
+        case 1: fir64<4, SPL, 6>(x, hp, cw, order, shift, len); break;
+        case 2: fir64<8, SPL, 6>(x, hp, cw, order, shift, len); break;
+        case 3: fir64<12, SPL, 6>(x, hp, cw, order, shift, len); break;
+        default: fir64<16, SPL, 6>(x, hp, cw, order, shift, len); break;
         }
     } else {  // FIXED: iterated differences in place (encode.rs:3039-3060)
         int32_t h[4];
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            const int32_t t = __shfl_up(x[60 + kk], 1, 64);
+            const int32_t t = __shfl_up(x[SPL - 4 + kk], 1, 64);
             h[kk] = lane ? t : 0;
         }
         int32_t q0 = h[3], q1 = h[3] - h[2], q2 = q1 - (h[2] - h[1]);
         int32_t q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
 #pragma unroll
-        for (int e = 0; e < 64; e++) {
+        for (int e = 0; e < SPL; e++) {
             const int32_t e1 = x[e] - q0, e2 = e1 - q1, e3 = e2 - q2, e4 = e3 - q3;
             q0 = x[e]; q1 = e1; q2 = e2; q3 = e3;
             x[e] = len(e, order == 0 ? x[e] : order == 1 ? e1 : order == 2 ? e2 : order == 3 ? e3 : e4);
@@ -3221,8 +3219,8 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         lds_put(sb, resid_pos + 2, porder, 4);
     }
     const uint32_t pos = resid_pos + 6;
-    const bool head = ((64u * lane) & (plen - 1u)) == 0;   // this lane starts a partition
-    const uint32_t cnt = 64u - first;
+    const bool head = (lane & ((1u << lpp) - 1u)) == 0;   // this lane starts a partition
+    const uint32_t cnt = (uint32_t)SPL - first;
     const uint32_t mybits = (head ? hb + (rice ? 0u : 5u) : 0u) + (rice ? len.qsum + cnt * (k + 1u) : cnt * eb);
     const uint32_t incl = wave_scan_u32(mybits);
     br.init(sb, pos + incl - mybits);
@@ -3233,7 +3231,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     if (rice) {
         const uint32_t stop = 1u << k, lowmask = stop - 1u;
 #pragma unroll
-        for (int e = 0; e < 64; e++) {
+        for (int e = 0; e < SPL; e++) {
             if (e >= 16 || (uint32_t)e >= first) {
                 const uint32_t u = (uint32_t)x[e];
                 uint32_t qn = u >> k;
@@ -3251,14 +3249,15 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     } else if (eb) {
         const uint32_t emask = eb >= 32 ? 0xFFFFFFFFu : (1u << eb) - 1u;
 #pragma unroll
-        for (int e = 0; e < 64; e++)
+        for (int e = 0; e < SPL; e++)
             if (e >= 16 || (uint32_t)e >= first) br.put((uint32_t)x[e] & emask, eb);
     }
     br.finish();
 }
 
-template <int NT>
+template <int NT, int SPL>
 __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
+    constexpr uint32_t N = 64u * SPL;
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ __attribute__((aligned(16))) uint16_t T[4][256];  // slicing-by-4 tables
     __shared__ uint32_t part[4];
@@ -3267,7 +3266,7 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     const uint32_t ch = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *fb = reinterpret_cast<uint32_t *>(lds);
     const uint64_t fn = q.first_frame_number + frame;
-    const HeaderCodes hc = header_codes(FN, q.sample_rate, fn);
+    const HeaderCodes hc = header_codes(N, q.sample_rate, fn);
     const uint64_t begin = q.frame_off[frame];
     const uint32_t flen = (uint32_t)(q.frame_off[frame + 1] - begin);  // bytes, CRC-16 included
     const uint32_t nwords = (flen + 3) / 4 + 1;
@@ -3293,8 +3292,8 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
             hdr[kk++] = (uint8_t)(lead | (uint32_t)(fn >> (6 * (nb - 1))));
             for (int b = (int)nb - 2; b >= 0; b--) hdr[kk++] = (uint8_t)(0x80 | ((fn >> (6 * b)) & 0x3F));
         }
-        if (hc.bextra_bits == 8) hdr[kk++] = (uint8_t)(FN - 1);
-        else if (hc.bextra_bits == 16) { hdr[kk++] = (uint8_t)((FN - 1) >> 8); hdr[kk++] = (uint8_t)(FN - 1); }
+        if (hc.bextra_bits == 8) hdr[kk++] = (uint8_t)(N - 1);
+        else if (hc.bextra_bits == 16) { hdr[kk++] = (uint8_t)((FN - 1) >> 8); hdr[kk++] = (uint8_t)(N - 1); }
         if (hc.rextra_bits == 8) hdr[kk++] = (uint8_t)hc.rextra;
         else if (hc.rextra_bits == 16) { hdr[kk++] = (uint8_t)(hc.rextra >> 8); hdr[kk++] = (uint8_t)hc.rextra; }
         uint32_t crc = 0;  // CRC-8, poly 0x07 (crc.rs:99-128)
@@ -3307,7 +3306,7 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     }
     uint32_t start_bit = header_bytes(hc) * 8;
     for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
-    if (!(p.dbg & 2)) wave_subframe(p, frame, ch, fb, start_bit);
+    if (!(p.dbg & 2)) wave_subframe<SPL>(p, frame, ch, fb, start_bit);
     __syncthreads();
     // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4)).
     // One pass: the frame, left-padded with zero bytes (they leave a zero CRC state unchanged) to
@@ -3808,6 +3807,43 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
 // never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
 size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_size) * 4; }
 
+// block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
+#define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
+bool wave_block_size(uint32_t B) {
+    switch (B) {
+#define X(n, spl) case n:
+        FLACGPU_WAVE_SIZES(X)
+#undef X
+        return true;
+    default: return false;
+    }
+}
+void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+    switch (B) {
+#define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl>), dim3(blocks), dim3(WG), 0, st, p); break;
+        FLACGPU_WAVE_SIZES(X)
+#undef X
+    default: break;
+    }
+}
+template <int SPL>
+void launch_frame64_spl(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
+    switch (p.channels) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64, SPL>), dim3(frames), dim3(64), lds, st, p, q); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128, SPL>), dim3(frames), dim3(128), lds, st, p, q); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192, SPL>), dim3(frames), dim3(192), lds, st, p, q); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256, SPL>), dim3(frames), dim3(256), lds, st, p, q); break;
+    }
+}
+void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
+    switch (B) {
+#define X(n, spl) case n: launch_frame64_spl<spl>(p, q, frames, lds, st); break;
+        FLACGPU_WAVE_SIZES(X)
+#undef X
+    default: break;
+    }
+}
+
 template <int NL>
 void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                       const double *win, hipStream_t st) {
@@ -4082,17 +4118,19 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
     // block sizes, a short last frame, candidates wider than 25 bits) the generic LDS ones
-    const bool fast16 = (B == FN) && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
-    const uint32_t n_fast = fast16 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
+    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
+    // wave-per-candidate kernel (FIXED + LPC analysis of a candidate in one wave, after the LPC
+    // parameters are known): block lengths 64 x {16, 18, 32, 36, 64}, LPC order <= 16
+    const bool w64 = narrow && wave_block_size(B) && p.max_lpc_order <= 16 && p.max_po <= 6 &&
+                     !getenv("FLACGPU_NO_W64");
+    const bool fast16 = narrow && B == FN;  // 16-samples-per-lane register kernels (any order)
+    const uint32_t n_fast = (w64 || fast16) ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
     Params pf = p, pg = p;
     pf.f0 = 0;
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = n_frames - n_fast;
     const bool lpc = p.max_lpc_order > 0;
-    // frames on the register path with LPC order <= 16 take the wave-per-candidate kernel
-    // (FIXED + LPC analysis of a candidate in one wave, after the LPC parameters are known)
-    const bool w64 = n_fast && p.max_lpc_order <= 16 && p.max_po <= 6 && !getenv("FLACGPU_NO_W64");
     // Otherwise the FIXED analysis and the autocorrelation -> Levinson chain, which only share
     // their input, run concurrently on two HIP streams (fork after k_candinfo, join before
     // k_fir).  With per-kernel timing enabled everything is serialised on one stream.
@@ -4124,9 +4162,9 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         }
         if (pg.fcount) hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
-    if (w64) {
+    if (w64 && pf.fcount) {
         begin(11);
-        hipLaunchKernelGGL(k_cand64, dim3((pf.fcount * c->ncand + 3) / 4), dim3(WG), 0, st, pf);
+        launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
     }
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
@@ -4221,12 +4259,17 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     // from the PCM, CRC-16 from LDS, one write of the finished bytes); any other frame goes
     // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
     // atomic OR at shared words) -> k_crc
-    const bool fast16 = p.block_size == FN && (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
-                        !getenv("FLACGPU_NO_FAST");
-    const uint32_t n_fast = fast16 ? (p.last_len == p.block_size ? p.n_frames : p.n_frames - 1) : 0;
-    const uint32_t fbw = frame_fb_words(p.channels, c->bps);
+    const uint32_t B = p.block_size;
+    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
+    const bool fast16 = narrow && B == FN;  // k_frame / k_pack<2,*>: 4096 only, any order
+    const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
     const size_t lds_frame = ((size_t)fbw + WG * 20) * sizeof(int32_t);
-    const bool fused = n_fast && lds_frame <= 64 * 1024 && !getenv("FLACGPU_NO_FUSED_PACK");
+    // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}, order <= 16, <= 4 channels
+    const bool f64w = narrow && wave_block_size(B) && p.max_lpc_order <= 16 && p.channels <= 4 &&
+                      p.max_po <= 6 && (size_t)fbw * sizeof(int32_t) <= 64 * 1024 &&
+                      !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64");
+    const uint32_t n_fast = (fast16 || f64w) ? (p.last_len == B ? p.n_frames : p.n_frames - 1) : 0;
+    const bool fused = n_fast && (f64w || (lds_frame <= 64 * 1024 && !getenv("FLACGPU_NO_FUSED_PACK")));
     Params pf = p, pg = p;
     pf.f0 = 0;
     pf.fcount = n_fast;
@@ -4237,16 +4280,8 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     if (c->timing) (void)hipEventRecord(ev[1], st);
     {
         const size_t lds = pack_lds_bytes(p.block_size);
-        const bool f64w = fused && p.max_lpc_order <= 16 && p.channels <= 4 && p.max_po <= 6 &&
-                          !getenv("FLACGPU_NO_FRAME64");
         if (pf.fcount && f64w) {  // wave per subframe
-            const size_t l64 = (size_t)fbw * sizeof(int32_t);
-            switch (p.channels) {
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64>), dim3(pf.fcount), dim3(64), l64, st, pf, q); break;
-            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128>), dim3(pf.fcount), dim3(128), l64, st, pf, q); break;
-            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192>), dim3(pf.fcount), dim3(192), l64, st, pf, q); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256>), dim3(pf.fcount), dim3(256), l64, st, pf, q); break;
-            }
+            launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
         } else if (pf.fcount && fused) {
             if (p.max_lpc_order <= 16)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<1>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
@@ -4314,9 +4349,9 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
                           void *stream) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     const uint32_t B = c->opts.block_size;
-    const uint32_t fbw = frame_fb_words(c->channels, c->bps);
+    const uint32_t fbw = frame_fb_words(c->channels, c->bps, B);
     const bool eligible =
-        d_pcm && n_frames >= 256 && n_frames <= c->max_frames && last_len == B && B == FN &&
+        d_pcm && n_frames >= 256 && n_frames <= c->max_frames && last_len == B && wave_block_size(B) &&
         (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && c->opts.max_lpc_order <= 16 &&
         c->opts.max_partition_order <= 6 && c->channels <= 4 && (layout == 0 || layout == 1) &&
         (size_t)fbw * sizeof(int32_t) <= 64 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
@@ -4371,18 +4406,13 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
             dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
             hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, r);
         }
-        hipLaunchKernelGGL(k_cand64, dim3((ncb + 3) / 4), dim3(WG), 0, st, r);
+        launch_cand64(r, B, (ncb + 3) / 4, st);
         hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's
         if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
         hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, r, q);
         if (!half) HIP_TRY(hipEventRecord(c->ev_layout, st));
-        switch (p.channels) {
-        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64>), dim3(r.fcount), dim3(64), l64, st, r, q); break;
-        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128>), dim3(r.fcount), dim3(128), l64, st, r, q); break;
-        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192>), dim3(r.fcount), dim3(192), l64, st, r, q); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256>), dim3(r.fcount), dim3(256), l64, st, r, q); break;
-        }
+        launch_frame64(r, q, B, r.fcount, l64, st);
     }
     HIP_TRY(hipEventRecord(c->ev_join, st1));
     HIP_TRY(hipStreamWaitEvent(st0, c->ev_join, 0));

@@ -128,3 +128,16 @@ def test_two_range_pipeline_matches_serial(channels, bps, max_po, max_lpc, exhau
         rc, fb, _ = orc.encode_frame(oopts, rate, bps, frames[f], frame_number=first + f)
         assert rc == 0 and pip_bytes[pip_off[f]:pip_off[f + 1]] == fb, f"frame {f}"
     an.close()
+
+
+@pytest.mark.parametrize("block", [1024, 1152, 2048, 2304])
+def test_wave_kernels_other_block_sizes(block):
+    """The wave kernels (k_cand64 / k_frame64) are instantiated for 64 x {16, 18, 32, 36, 64}
+    samples; every frame is compared with the oracle and the host packer (run_case)."""
+    run_case(synth_fast(400 + block, 2, 24, block * 7), 2, 24, block_size=block)                      # best
+    run_case(synth_fast(401 + block, 2, 16, block * 5 + 77), 2, 16, block_size=block, max_po=5,
+             max_lpc=8, exhaustive=False, rate=44100)                                               # default + short last
+    run_case(synth_fast(402 + block, 2, 16, block * 4), 2, 16, block_size=block, max_po=3, max_lpc=0,
+             mid_side=False, exhaustive=False, rate=44100)                                          # Options::fast
+    run_case(synth_fast(403 + block, 1, 24, block * 3), 1, 24, block_size=block, max_lpc=16)         # mono, order 16
+    run_case(synth_fast(404 + block, 3, 20, block * 3), 3, 20, block_size=block, max_po=6, max_lpc=4)
