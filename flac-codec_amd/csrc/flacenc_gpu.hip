@@ -1873,7 +1873,11 @@ __device__ __forceinline__ uint64_t wave_total_u48(uint64_t v) {
 }
 // the previous lane's value, 0 on lane 0 (wave_shr:1)
 __device__ __forceinline__ int32_t lane_prev(int32_t v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+    // keep it a v_mov_b32_dpp: folded into a consumer (v_sub_u32_dpp ... wave_shr:1) the halo of
+    // the FIXED differences came out wrong on gfx950 (tests/test_gpu_pack.py, FIXED-only cases)
+    asm volatile("" : "+v"(r));
+    return r;
 }
 __device__ __forceinline__ uint32_t sread(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
@@ -3198,10 +3202,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     } else {  // FIXED: iterated differences in place (encode.rs:3039-3060)
         int32_t h[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int32_t t = __shfl_up(x[SPL - 4 + kk], 1, 64);
-            h[kk] = lane ? t : 0;
-        }
+        for (int kk = 0; kk < 4; kk++) h[kk] = lane_prev(x[SPL - 4 + kk]);
         int32_t q0 = h[3], q1 = h[3] - h[2], q2 = q1 - (h[2] - h[1]);
         int32_t q3 = q2 - ((h[2] - h[1]) - (h[1] - h[0]));
 #pragma unroll
