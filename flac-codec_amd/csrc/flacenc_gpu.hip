@@ -610,6 +610,51 @@ __global__ void __launch_bounds__(WG) k_orbits(Params p, uint32_t *__restrict__ 
     }
 }
 
+// interleaved input with C independent channels (ncand == C): one pass splits the channels into
+// planar rows and ORs every channel's samples (orbits -> wasted bits / all-zero)
+template <int C>
+__global__ void __launch_bounds__(WG) k_deinterleave_n(const int32_t *__restrict__ in,
+                                                       int32_t *__restrict__ out, uint32_t block_size,
+                                                       uint32_t ldb, uint32_t n_frames, uint32_t last_len,
+                                                       uint32_t *__restrict__ orbits, uint32_t f0) {
+    const uint32_t frame = f0 + blockIdx.y;
+    const uint32_t n = (frame + 1 == n_frames) ? last_len : block_size;
+    const int32_t *src = in + (size_t)frame * block_size * C;
+    int32_t *o = out + (size_t)frame * C * ldb;
+    uint32_t acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0;
+    for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < n; i += gridDim.x * WG) {
+        int32_t v[C];
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < C / 4; q++) {
+                const int4 t = reinterpret_cast<const int4 *>(src + (size_t)i * C)[q];
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else if constexpr (C % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < C / 2; q++) {
+                const int2 t = reinterpret_cast<const int2 *>(src + (size_t)i * C)[q];
+                v[2 * q] = t.x; v[2 * q + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) v[c] = src[(size_t)i * C + c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            o[(size_t)c * ldb + i] = v[c];
+            acc[c] |= (uint32_t)v[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t v = wave_or_u32(acc[c]);
+        if ((threadIdx.x & 63) == 0 && v) atomicOr(&orbits[(size_t)frame * C + c], v);
+    }
+}
+
 // per (frame, candidate): activity, wasted bits, effective bps (encode.rs:2870-2898)
 __global__ void __launch_bounds__(WG) k_candinfo(Params p, const uint32_t *__restrict__ orbits) {
     const uint32_t idx = p.f0 * p.ncand + blockIdx.x * WG + threadIdx.x;
@@ -3808,6 +3853,31 @@ int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
 // never longer than its VERBATIM form: <= 40 + 33 n bits, plus the 16-byte frame header)
 size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_size) * 4; }
 
+// K0 for frames [f0, f0 + fcount): split the channels into planar rows and OR every candidate's
+// samples.  Returns true when the orbits are already accumulated.
+bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames, uint32_t last_len,
+               uint32_t f0, uint32_t fcount, hipStream_t st) {
+    const uint32_t B = c->opts.block_size;
+    const dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), fcount);  // 8 samples per lane
+    if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
+        hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm, c->d_planar, B, c->ldb,
+                           n_frames, last_len, c->d_orbits, c->ncand, f0);
+        return true;
+    }
+    if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->ncand == c->channels) {
+        switch (c->channels) {
+#define X(C) case C: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_n<C>), grid, dim3(WG), 0, st, d_pcm, \
+                                        c->d_planar, B, c->ldb, n_frames, last_len, c->d_orbits, f0); return true;
+            X(1) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+        default: break;
+        }
+    }
+    hipLaunchKernelGGL(k_deinterleave, grid, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels, B, c->ldb,
+                       n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR, f0);
+    return false;
+}
+
 // block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
 #define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
 bool wave_block_size(uint32_t B) {
@@ -4098,15 +4168,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     if (planar_direct) {
         p.planar = d_pcm;  // [frame][ch][B] with ldb == B
     } else {
-        dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames);  // 8 samples per lane
-        if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
-            hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm,
-                               c->d_planar, B, c->ldb, n_frames, last_len, c->d_orbits, c->ncand, 0u);
-            have_orbits = true;
-        } else {
-            hipLaunchKernelGGL(k_deinterleave, grid, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels,
-                               B, c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR, 0u);
-        }
+        have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, 0, n_frames, st);
     }
     if (!have_orbits)
         hipLaunchKernelGGL(k_orbits, dim3(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames), dim3(WG), 0, st, p,
@@ -4390,16 +4452,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         const uint32_t ncb = r.fcount * c->ncand;
         const dim3 g0(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), r.fcount);
         bool have_orbits = false;
-        if (!planar_direct) {
-            if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
-                hipLaunchKernelGGL(k_deinterleave2, g0, dim3(WG), 0, st, (const int2 *)d_pcm, c->d_planar, B,
-                                   c->ldb, n_frames, last_len, c->d_orbits, c->ncand, r.f0);
-                have_orbits = true;
-            } else {
-                hipLaunchKernelGGL(k_deinterleave, g0, dim3(WG), 0, st, d_pcm, c->d_planar, c->channels, B,
-                                   c->ldb, n_frames, last_len, layout == FLACGPU_LAYOUT_PLANAR, r.f0);
-            }
-        }
+        if (!planar_direct) have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, r.f0, r.fcount, st);
         if (!have_orbits) hipLaunchKernelGGL(k_orbits, g0, dim3(WG), 0, st, r, c->d_orbits);
         if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats, dim3(r.fcount), dim3(WG), 0, st, r);
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits);
