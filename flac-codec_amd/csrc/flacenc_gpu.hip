@@ -905,7 +905,6 @@ constexpr int AC_LD = 36;  // row stride of the ac buffer (max H)
 // ---------------------------------------------------------------------------------
 constexpr int AC3_TS = 32;            // samples per tile
 constexpr int AC3_LD = AC3_TS + 4;    // int row stride: 16-byte aligned, rows spread over banks
-constexpr int AC3_ROWS = 32;          // 16 frames x (L, R)
 
 template <int A, int LG, bool FIRST>
 __device__ __forceinline__ void ac3_block(const double (&w)[16], const double (&prev)[16],
@@ -964,45 +963,51 @@ __device__ __forceinline__ void ac3_convert(const Ac3Raw &r, int32_t cb, uint32_
 }
 
 
-// per-lane constants + staging registers of one wave
+// per-lane constants + staging registers of one wave; ROWS = staged rows per tile (32: the L/R rows
+// of 16 stereo frames, 64: one row per candidate for independent channels)
+template <int ROWS>
 struct Ac3Lane {
-    const int32_t *gsrc[4];   // global source of this lane's 4 staged int4 (tile 0)
-    const double *wsrc;       // window slice source (2 f64 per lane of each 16-lane group)
-    uint32_t sdst[4];         // LDS destinations (ints, within a buffer)
+    static constexpr int NIT = ROWS / 8;
+    static constexpr int RAW = ROWS * AC3_LD;       // ints of raw rows per buffer
+    static constexpr int BUF = RAW + 2 * AC3_TS;    // + the window slice (f64)
+    const int32_t *gsrc[NIT];  // global source of this lane's staged int4s (tile 0)
+    const double *wsrc;        // window slice source (2 f64 per lane of each 16-lane group)
+    uint32_t sdst[NIT];        // LDS destinations (ints, within a buffer)
     uint32_t wdst;
     uint32_t off_a, off_b;    // LDS offsets of the candidate's two source rows
     int32_t cb;
     uint32_t sh;
     uint32_t ntiles;
-    int4 stage[4];
+    int4 stage[NIT];
     double2 wstage;
 };
-__device__ __forceinline__ void ac3_fetch(Ac3Lane &L, uint32_t t) {
+template <int ROWS>
+__device__ __forceinline__ void ac3_fetch(Ac3Lane<ROWS> &L, uint32_t t) {
     t = t < L.ntiles ? t : L.ntiles - 1;
 #pragma unroll
-    for (int it = 0; it < 4; it++) L.stage[it] = *reinterpret_cast<const int4 *>(L.gsrc[it] + t * AC3_TS);
+    for (int it = 0; it < ROWS / 8; it++) L.stage[it] = *reinterpret_cast<const int4 *>(L.gsrc[it] + t * AC3_TS);
     L.wstage = *reinterpret_cast<const double2 *>(L.wsrc + t * AC3_TS);
 }
-__device__ __forceinline__ void ac3_commit(const Ac3Lane &L, int32_t *dst) {
+template <int ROWS>
+__device__ __forceinline__ void ac3_commit(const Ac3Lane<ROWS> &L, int32_t *dst) {
 #pragma unroll
-    for (int it = 0; it < 4; it++) *reinterpret_cast<int4 *>(dst + L.sdst[it]) = L.stage[it];
+    for (int it = 0; it < ROWS / 8; it++) *reinterpret_cast<int4 *>(dst + L.sdst[it]) = L.stage[it];
     *reinterpret_cast<double2 *>(dst + L.wdst) = L.wstage;
 }
 __device__ __forceinline__ void ac3_sync() {  // LDS operations of one wave execute in order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-constexpr int AC3_RAW = AC3_ROWS * AC3_LD;       // ints of raw rows per buffer
-constexpr int AC3_BUF = AC3_RAW + 2 * AC3_TS;    // + the window slice (f64)
 
 // Software pipeline per tile of 32 samples (two blocks of 16):
 //   block 0: prefetch block 1's operands from LDS, convert + accumulate block 0
 //   block 1: commit tile t+1 (fetched one whole tile ago) into the other buffer, start the
 //            global fetch of tile t+2, prefetch the next tile's block 0, accumulate block 1
-template <int A, int LG, bool FIRST>
-__device__ __forceinline__ void ac3_tile(Ac3Lane &L, int32_t *tile, uint32_t t, Ac3Raw &r0, Ac3Raw &r1,
+template <int A, int LG, bool FIRST, int ROWS>
+__device__ __forceinline__ void ac3_tile(Ac3Lane<ROWS> &L, int32_t *tile, uint32_t t, Ac3Raw &r0, Ac3Raw &r1,
                                          double (&w0)[16], double (&w1)[16], double (&acc)[LG]) {
     const uint32_t buf = t & 1;
+    constexpr int AC3_RAW = Ac3Lane<ROWS>::RAW, AC3_BUF = Ac3Lane<ROWS>::BUF;
     int32_t *cur = tile + buf * AC3_BUF, *nxt = tile + (buf ^ 1) * AC3_BUF;
     ac3_load(cur + L.off_a, cur + L.off_b, reinterpret_cast<const double *>(cur + AC3_RAW), 16, r1);
     __builtin_amdgcn_sched_barrier(0);
@@ -1019,37 +1024,53 @@ __device__ __forceinline__ void ac3_tile(Ac3Lane &L, int32_t *tile, uint32_t t, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int A, int LG>
-__device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][AC3_BUF] */,
+template <int A, int LG, bool STEREO>
+__device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][BUF] */,
                                          uint32_t frame0, uint32_t nframes, uint32_t n,
                                          const double *__restrict__ win, uint32_t group) {
+    constexpr int ROWS = STEREO ? 32 : 64;
+    constexpr int AC3_RAW = Ac3Lane<ROWS>::RAW;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t total = nframes * 4;
+    const uint32_t total = nframes * p.ncand;            // candidates of this launch
     const uint32_t cand0 = group * 64;
     const bool live = cand0 + lane < total;
-    const uint32_t f_lo = cand0 / 4;                       // first frame of this wave (relative)
-    const uint32_t fl = lane >> 2, cand = lane & 3;        // frame within the wave, candidate
-    const uint32_t f_last = nframes - 1;
-    const uint32_t frame = frame0 + (f_lo + fl < nframes ? f_lo + fl : f_last);
-    const CandInfo ci = p.cinfo[(size_t)frame * 4 + cand];
+    const uint32_t cc = live ? cand0 + lane : total - 1;  // clamped: results of dead lanes are dropped
+    const uint32_t frame = frame0 + cc / p.ncand, cand = cc % p.ncand;
+    const CandInfo ci = p.cinfo[(size_t)frame * p.ncand + cand];
     const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
-    Ac3Lane L;
-    // candidate = (a + cb * b) >> sh over the frame's rows L (2 fl) and R (2 fl + 1)
-    L.off_a = (2 * fl + (cand == 1 ? 1u : 0u)) * AC3_LD;
-    L.off_b = (2 * fl + 1) * AC3_LD;
-    L.cb = cand == 2 ? 1 : cand == 3 ? -1 : 0;
-    L.sh = wasted + (cand == 2 ? 1u : 0u);
-    L.ntiles = n / AC3_TS;
-    // staging: lane -> (row = it * 8 + lane / 8, 4 samples at column 4 * (lane % 8)); the window
-    // slice (32 f64) is staged by every group of 16 lanes (identical data, same addresses)
+    Ac3Lane<ROWS> L;
     const uint32_t srow = lane >> 3, scol = (lane & 7) * 4;
+    if constexpr (STEREO) {
+        // candidate = (a + cb * b) >> sh over the frame's rows L (2 fl) and R (2 fl + 1)
+        const uint32_t f_lo = cand0 / 4, fl = lane >> 2, f_last = nframes - 1;
+        L.off_a = (2 * fl + (cand == 1 ? 1u : 0u)) * AC3_LD;
+        L.off_b = (2 * fl + 1) * AC3_LD;
+        L.cb = cand == 2 ? 1 : cand == 3 ? -1 : 0;
+        L.sh = wasted + (cand == 2 ? 1u : 0u);
+        // staging: lane -> (row = it * 8 + lane / 8, 4 samples at column 4 * (lane % 8))
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const uint32_t r = it * 8 + srow;                  // 0..31: frame r / 2, channel r & 1
-        const uint32_t fr = f_lo + r / 2 < nframes ? f_lo + r / 2 : f_last;
-        L.gsrc[it] = p.planar + ((size_t)(frame0 + fr) * 2 + (r & 1)) * p.ldb + scol;
-        L.sdst[it] = r * AC3_LD + scol;
+        for (int it = 0; it < ROWS / 8; it++) {
+            const uint32_t r = it * 8 + srow;              // 0..31: frame r / 2, channel r & 1
+            const uint32_t fr = f_lo + r / 2 < nframes ? f_lo + r / 2 : f_last;
+            L.gsrc[it] = p.planar + ((size_t)(frame0 + fr) * 2 + (r & 1)) * p.ldb + scol;
+            L.sdst[it] = r * AC3_LD + scol;
+        }
+    } else {
+        // independent channels: candidate g of the launch is planar row frame0 * C + g
+        L.off_a = lane * AC3_LD;
+        L.off_b = L.off_a;
+        L.cb = 0;
+        L.sh = wasted;
+#pragma unroll
+        for (int it = 0; it < ROWS / 8; it++) {
+            const uint32_t r = it * 8 + srow;              // 0..63: candidate cand0 + r
+            const uint32_t g = cand0 + r < total ? cand0 + r : total - 1;
+            L.gsrc[it] = p.planar + ((size_t)frame0 * p.channels + g) * p.ldb + scol;
+            L.sdst[it] = r * AC3_LD + scol;
+        }
     }
+    L.ntiles = n / AC3_TS;
+    // the window slice (32 f64) is staged by every group of 16 lanes (identical data, same addresses)
     L.wsrc = win + 2 * (lane & 15);
     L.wdst = AC3_RAW + 4 * (lane & 15);
     double acc[LG];
@@ -1066,29 +1087,29 @@ __device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][A
 #pragma unroll 1
     for (uint32_t t = 1; t < L.ntiles; t++) ac3_tile<A, LG, false>(L, tile, t, r0, r1, w0, w1, acc);
     if (live) {
-        double *out = p.ac + ((size_t)frame * 4 + cand) * AC_LD + A;
+        double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
 #pragma unroll
         for (int k = 0; k < LG; k++) out[k] = acc[k];
     }
 }
 
 // NL lags split over NS waves; lag ranges are [NL * w / NS, NL * (w + 1) / NS)
-template <int NL, int NS>
+template <int NL, int NS, bool STEREO>
 __global__ void __launch_bounds__(64 * NS)
 k_autocorr3(Params p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *__restrict__ win) {
-    __shared__ __attribute__((aligned(16))) int32_t tiles[NS][2 * AC3_BUF];
+    __shared__ __attribute__((aligned(16))) int32_t tiles[NS][2 * Ac3Lane<STEREO ? 32 : 64>::BUF];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int32_t *tile = tiles[wave];
     constexpr int B0 = 0, B1 = NL * 1 / NS, B2 = NL * 2 / NS, B3 = NL * 3 / NS, B4 = NL * 4 / NS;
     if constexpr (NS == 2) {
-        if (wave == 0) ac3_wave<B0, B1 - B0>(p, tile, frame0, nframes, n, win, blockIdx.x);
-        else ac3_wave<B1, B2 - B1>(p, tile, frame0, nframes, n, win, blockIdx.x);
+        if (wave == 0) ac3_wave<B0, B1 - B0, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x);
+        else ac3_wave<B1, B2 - B1, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x);
     } else {
         switch (wave) {
-        case 0: ac3_wave<B0, B1 - B0>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
-        case 1: ac3_wave<B1, B2 - B1>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
-        case 2: ac3_wave<B2, B3 - B2>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
-        default: ac3_wave<B3, B4 - B3>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        case 0: ac3_wave<B0, B1 - B0, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        case 1: ac3_wave<B1, B2 - B1, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        case 2: ac3_wave<B2, B3 - B2, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+        default: ac3_wave<B3, B4 - B3, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
         }
     }
 }
@@ -3915,34 +3936,45 @@ void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t f
     }
 }
 
-template <int NL>
+template <int NL, bool STEREO>
 void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                       const double *win, hipStream_t st) {
-    const uint32_t groups = (nframes * 4 + 63) / 64;
+    const uint32_t groups = (nframes * p.ncand + 63) / 64;
     // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
     // SIMD to issue at full rate and 8192 frames are only 512 candidate groups (0.23 ms against
     // 0.31 ms split 2 ways).  When other contexts keep the SIMDs busy anyway, the 2-way split wins:
     // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
     // instructions).
     if (p.ac_split == 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2>), dim3(groups), dim3(128), 0, st, p, frame0,
-                           nframes, n, win);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
+                           frame0, nframes, n, win);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4>), dim3(groups), dim3(256), 0, st, p, frame0,
-                           nframes, n, win);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
+                           frame0, nframes, n, win);
 }
-// stereo L/R/M/S candidates, <= 24-bit samples, frame length a multiple of 32, order <= 16
+template <bool STEREO>
+void launch_autocorr3_nl(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+                         hipStream_t st) {
+    const uint32_t nl = p.max_lpc_order + 1;
+    if (nl <= 5) launch_autocorr3<5, STEREO>(p, frame0, nframes, n, win, st);
+    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, frame0, nframes, n, win, st);
+    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, frame0, nframes, n, win, st);
+    else launch_autocorr3<17, STEREO>(p, frame0, nframes, n, win, st);
+}
+// frame length a multiple of 32, order <= 16, and either stereo L/R/M/S candidates of <= 24-bit
+// samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
 bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
                    hipStream_t st) {
-    if (!p.stereo4 || p.ncand != 4 || p.channels != 2 || p.bps > 24 || n < 32 || n % 32 != 0 ||
-        p.max_lpc_order > 16 || getenv("FLACGPU_NO_AC3"))
-        return false;
-    const uint32_t nl = p.max_lpc_order + 1;
-    if (nl <= 5) launch_autocorr3<5>(p, frame0, nframes, n, win, st);
-    else if (nl <= 9) launch_autocorr3<9>(p, frame0, nframes, n, win, st);
-    else if (nl <= 13) launch_autocorr3<13>(p, frame0, nframes, n, win, st);
-    else launch_autocorr3<17>(p, frame0, nframes, n, win, st);
-    return true;
+    if (n < 32 || n % 32 != 0 || p.max_lpc_order > 16 || getenv("FLACGPU_NO_AC3")) return false;
+    if (p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24) {
+        launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
+        return true;
+    }
+    if (!p.stereo4 && p.ncand == p.channels) {
+        launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
+        return true;
+    }
+    return false;
 }
 
 template <int H>
