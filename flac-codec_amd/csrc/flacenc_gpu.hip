@@ -2988,7 +2988,7 @@ __constant__ CrcWeights kCrcW = CrcWeights();
 
 // W17[k] = x^(544 k) mod P: weight of a 68-byte slice that is followed by k more slices
 struct CrcWeights17 {
-    uint16_t w[WG + 1];
+    uint16_t w[512 + 1];
     constexpr CrcWeights17() : w() {
         uint32_t x32 = 0x100;                       // x^8
         x32 = gf_mulmod_c(x32, x32);                // x^16
@@ -2996,7 +2996,7 @@ struct CrcWeights17 {
         uint32_t x544 = 1;
         for (int i = 0; i < 17; i++) x544 = gf_mulmod_c(x544, x32);
         uint32_t v = 1;
-        for (int k = 0; k <= WG; k++) {
+        for (int k = 0; k <= 512; k++) {
             w[k] = (uint16_t)v;
             v = gf_mulmod_c(v, x544);
         }
@@ -3327,7 +3327,7 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     constexpr uint32_t N = 64u * SPL;
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ __attribute__((aligned(16))) uint16_t T[4][256];  // slicing-by-4 tables
-    __shared__ uint32_t part[4];
+    __shared__ uint32_t part[NT / 64];
     __shared__ uint8_t hdr[16];
     const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
     const uint32_t ch = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3918,13 +3918,33 @@ void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
     default: break;
     }
 }
+template <int NT, int SPL>
+void launch_frame64_nt(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
+    static bool big_lds = false;  // frames of 5..8 channels need more than the default 64 KB
+    if (lds > 64 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute((const void *)k_frame64<NT, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<NT, SPL>), dim3(frames), dim3(NT), lds, st, p, q);
+}
 template <int SPL>
 void launch_frame64_spl(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
     switch (p.channels) {
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<64, SPL>), dim3(frames), dim3(64), lds, st, p, q); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<128, SPL>), dim3(frames), dim3(128), lds, st, p, q); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<192, SPL>), dim3(frames), dim3(192), lds, st, p, q); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<256, SPL>), dim3(frames), dim3(256), lds, st, p, q); break;
+    case 1: launch_frame64_nt<64, SPL>(p, q, frames, lds, st); break;
+    case 2: launch_frame64_nt<128, SPL>(p, q, frames, lds, st); break;
+    case 3: launch_frame64_nt<192, SPL>(p, q, frames, lds, st); break;
+    case 4: launch_frame64_nt<256, SPL>(p, q, frames, lds, st); break;
+    default:
+        if constexpr (SPL == 64) {  // 5..8 channels: 4096-sample frames only
+            switch (p.channels) {
+            case 5: launch_frame64_nt<320, SPL>(p, q, frames, lds, st); break;
+            case 6: launch_frame64_nt<384, SPL>(p, q, frames, lds, st); break;
+            case 7: launch_frame64_nt<448, SPL>(p, q, frames, lds, st); break;
+            default: launch_frame64_nt<512, SPL>(p, q, frames, lds, st); break;
+            }
+        }
+        break;
     }
 }
 void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
@@ -4360,8 +4380,9 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
     const size_t lds_frame = ((size_t)fbw + WG * 20) * sizeof(int32_t);
     // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}, order <= 16, <= 4 channels
-    const bool f64w = narrow && wave_block_size(B) && p.max_lpc_order <= 16 && p.channels <= 4 &&
-                      p.max_po <= 6 && (size_t)fbw * sizeof(int32_t) <= 64 * 1024 &&
+    const bool f64w = narrow && wave_block_size(B) && p.max_lpc_order <= 16 &&
+                      (p.channels <= 4 || B == FN) && p.max_po <= 6 &&
+                      (size_t)fbw * sizeof(int32_t) <= 150 * 1024 &&
                       !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64");
     const uint32_t n_fast = (fast16 || f64w) ? (p.last_len == B ? p.n_frames : p.n_frames - 1) : 0;
     const bool fused = n_fast && (f64w || (lds_frame <= 64 * 1024 && !getenv("FLACGPU_NO_FUSED_PACK")));
@@ -4448,8 +4469,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     const bool eligible =
         d_pcm && n_frames >= 256 && n_frames <= c->max_frames && last_len == B && wave_block_size(B) &&
         (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && c->opts.max_lpc_order <= 16 &&
-        c->opts.max_partition_order <= 6 && c->channels <= 4 && (layout == 0 || layout == 1) &&
-        (size_t)fbw * sizeof(int32_t) <= 64 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
+        c->opts.max_partition_order <= 6 && (c->channels <= 4 || B == FN) && (layout == 0 || layout == 1) &&
+        (size_t)fbw * sizeof(int32_t) <= 150 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
         !getenv("FLACGPU_NO_W64") && !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64") &&
         c->two_ranges;
     if (!eligible) {
