@@ -141,3 +141,28 @@ def test_wave_kernels_other_block_sizes(block):
              mid_side=False, exhaustive=False, rate=44100)                                          # Options::fast
     run_case(synth_fast(403 + block, 1, 24, block * 3), 1, 24, block_size=block, max_lpc=16)         # mono, order 16
     run_case(synth_fast(404 + block, 3, 20, block * 3), 3, 20, block_size=block, max_po=6, max_lpc=4)
+
+
+@pytest.mark.parametrize("block", [1024, 1152, 2048, 2304, 4096])
+def test_wave_kernels_edge_inputs(block):
+    """Silence (CONSTANT), wasted bits, white noise / full-scale patterns (VERBATIM, escaped
+    partitions), 8-bit, half-silent frames -- through the wave kernels at every block length they
+    are instantiated for, every frame against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(500 + block))
+    run_case(np.zeros(block * 2 * 2, dtype=np.int32), 2, 16, block_size=block)
+    half = synth_fast(501 + block, 2, 16, block * 3)
+    half[block * 2:block * 4] = 0
+    run_case(half, 2, 16, block_size=block, max_po=5, max_lpc=8)
+    run_case((synth_fast(502 + block, 2, 16, block * 2) << 3).astype(np.int32), 2, 24, block_size=block)
+    run_case(rng.integers(-(1 << 23), 1 << 23, size=block * 2 * 2, dtype=np.int64).astype(np.int32), 2, 24,
+             block_size=block)
+    hi, lo = (1 << 23) - 1, -(1 << 23)
+    pat = np.array(([hi, lo, hi, hi, lo, lo, 0] * (block * 2 // 7 + 1))[:block * 2], dtype=np.int32)
+    run_case(pat, 2, 24, block_size=block)
+    run_case(pat, 1, 24, block_size=block)
+    run_case((synth_fast(503 + block, 2, 16, block * 2) >> 8).astype(np.int32), 2, 8, block_size=block)
+    # a lone loud click in silence: tiny partitions with k = 0 next to an escaped one
+    click = np.zeros(block * 2 * 2, dtype=np.int32)
+    click[block + 10] = 30000
+    click[block * 3 + 1] = -32768
+    run_case(click, 2, 16, block_size=block)
