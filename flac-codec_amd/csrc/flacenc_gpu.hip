@@ -3146,6 +3146,17 @@ struct BitRun {  // a lane's contiguous MSB-first bit run inside an LDS word arr
             word++;
         }
     }
+    // branch-free put for nb <= 32 with nb + (pending < 32) < 64: always one LDS OR (of 0 when no
+    // word was completed) -- no exec-mask juggling, 10 VALU instead of 8 VALU + 7 SALU
+    __device__ __forceinline__ void put_sel(uint32_t v, uint32_t nb) {
+        acc = (acc << nb) | v;
+        fill += nb;
+        const bool full = fill >= 32;
+        fill &= 31;
+        const uint32_t w = (uint32_t)(acc >> fill);
+        atomicOr(word, full ? w : 0u);
+        word += full ? 1 : 0;
+    }
     __device__ __forceinline__ void finish() {
         if (fill) atomicOr(word, (uint32_t)(acc << (32 - fill)));
     }
@@ -3239,15 +3250,17 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     const uint32_t first = lane == 0 ? order : 0u;
     const bool rice = k != 0xFF;
     struct LenAcc {
-        uint32_t qsum, ks, first;
+        uint32_t qsum, qmax, ks, first;
         bool rice;
         __device__ __forceinline__ int32_t operator()(int e, int32_t r) {
             uint32_t u = zigzag(r);
             if (e < 16) u = (uint32_t)e >= first ? u : 0u;
-            qsum += u >> ks;
+            const uint32_t q = u >> ks;
+            qsum += q;
+            qmax = q > qmax ? q : qmax;
             return rice ? (int32_t)u : r;
         }
-    } len{0u, rice ? k : 0u, first, rice};
+    } len{0u, 0u, rice ? k : 0u, first, rice};
     uint32_t resid_pos = body0 + order * bps;
     if (type == FLACGPU_SUB_LPC) {
         if (lane == 32) {
@@ -3295,7 +3308,23 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         if (rice) br.put(k, hb);
         else { br.put(esc_code, hb); br.put(eb, 5); }
     }
-    if (rice) {
+    // no code of the wave longer than 32 bits (the rule): one branch-free put per sample
+    const bool short_codes = !__any(rice && len.qmax + k + 1u > 32u);
+    if (rice && short_codes) {
+        const uint32_t stop = 1u << k, lowmask = stop - 1u, k1 = k + 1u;
+#pragma unroll
+        for (int e = 0; e < SPL; e++) {
+            const uint32_t u = (uint32_t)x[e];
+            uint32_t nb = (u >> k) + k1;
+            uint32_t v = stop | (u & lowmask);
+            if (e < 16) {  // warm-up samples of lane 0 carry no residual
+                nb = (uint32_t)e >= first ? nb : 0u;
+                v = (uint32_t)e >= first ? v : 0u;
+            }
+            br.put_sel(v, nb);
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (rice) {
         const uint32_t stop = 1u << k, lowmask = stop - 1u;
 #pragma unroll
         for (int e = 0; e < SPL; e++) {
