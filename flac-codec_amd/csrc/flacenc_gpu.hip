@@ -1500,6 +1500,162 @@ __global__ void __launch_bounds__(64) k_lpc(Params p) {
     out->shift = (uint8_t)(sh >= 0 ? sh : 0);
 }
 
+// Levinson-Durbin recursion up to `upto` orders (lp_coefficients, encode.rs:3536-3580), every loop
+// unrolled and guarded so that the arrays stay in registers
+template <int LMAX>
+__device__ __forceinline__ void levinson_u(const double (&acr)[LMAX + 1], uint32_t upto, double (&c)[LMAX],
+                                           double (&errs)[LMAX]) {
+    double cn[LMAX];
+    double k = acr[1] / acr[0];
+    c[0] = k;
+    double err = acr[0] * (1.0 - k * k);
+    errs[0] = err;
+#pragma unroll
+    for (int i = 1; i < LMAX; i++) {
+        if ((uint32_t)i < upto) {
+            double s = -0.0;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                double prod = acr[i - j] * c[j];
+                s = s + prod;
+            }
+            double q = acr[i + 1] - s;
+            double kk = q / err;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                double t = kk * c[i - 1 - j];
+                cn[j] = c[j] - t;
+            }
+            cn[i] = kk;
+#pragma unroll
+            for (int j = 0; j <= i; j++) c[j] = cn[j];
+            err = err * (1.0 - kk * kk);
+            errs[i] = err;
+        }
+    }
+}
+
+// K4 with max_lpc_order <= LMAX <= 16 known at compile time: with run-time loop bounds the
+// coefficient arrays sit in scratch memory and every access is a memory round trip
+template <int LMAX>
+__global__ void __launch_bounds__(64) k_lpc_u(Params p) {
+    const uint32_t idx = p.f0 * p.ncand + blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (p.f0 + p.fcount) * p.ncand) return;
+    const uint32_t frame = idx / p.ncand;
+    const uint32_t n = frame_len(p, frame);
+    const CandInfo ci = p.cinfo[idx];
+    LpcParams *out = p.lpc + idx;
+    if (!ci.active || ci.is_const) {
+        out->status = 1;
+        return;
+    }
+    const uint32_t L = p.max_lpc_order;
+    if (n <= L) {  // InsufficientLpcSamples, encode.rs:3300
+        out->status = 1;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    // precision table, encode.rs:3305-3315
+    const uint32_t precision = n <= 192 ? 7 : n <= 384 ? 8 : n <= 576 ? 9 : n <= 1152 ? 10
+                               : n <= 2304 ? 11 : n <= 4608 ? 12 : 13;
+    const double *ac = p.ac + (size_t)idx * AC_LD;
+    double acr[LMAX + 1], c[LMAX], errs[LMAX];
+#pragma unroll
+    for (int i = 0; i <= LMAX; i++) acr[i] = (uint32_t)i <= L ? ac[i] : 0.0;
+    // pass 1: errors of every order
+    levinson_u<LMAX>(acr, L, c, errs);
+    // compute_best_order, encode.rs:3656-3702 (bits-per-residual NOT clamped, :3675)
+    const double LN_2 = 0.693147180559945309417232121458176568;
+    const double error_scale = 0.5 / (double)n;
+    const double denom = 2.0 * LN_2;
+    int best = -1;
+    double best_bits = 0.0, second = 0.0;
+    bool have_second = false;
+    bool going = true;
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+        going = going && (uint32_t)i < L && errs[i] > 0.0;  // take_while(error > 0.0)
+        if (!going) continue;
+        uint32_t order = i + 1;
+        double header_bits = (double)(order * ((uint32_t)ci.bps + precision));
+        double bpr = log(errs[i] * error_scale) / denom;
+        double bits = __builtin_fma(bpr, (double)(n - order), header_bits);
+        if (best < 0) {
+            best = (int)i;
+            best_bits = bits;
+        } else if (total_key(bits) < total_key(best_bits)) {
+            second = best_bits;
+            have_second = true;
+            best = (int)i;
+            best_bits = bits;
+        } else if (!have_second || total_key(bits) < total_key(second)) {
+            second = bits;
+            have_second = true;
+        }
+    }
+    if (best < 0) {  // NoBestLpcOrder
+        out->status = 2;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    if (have_second && fabs(second - best_bits) <= 1e-9 * fabs(best_bits)) atomicAdd(&p.stats[1], 1u);
+    const uint32_t order = (uint32_t)best + 1;
+    // pass 2: coefficients of the chosen order (same recursion, same roundings)
+    levinson_u<LMAX>(acr, order, c, errs);
+    // quantize, encode.rs:3334-3401
+    const int32_t max_coeff = (1 << (precision - 1)) - 1, min_coeff = -(1 << (precision - 1));
+    double l = fabs(c[0]);
+#pragma unroll
+    for (int i = 1; i < LMAX; i++) {
+        if ((uint32_t)i < order) {
+            double a = fabs(c[i]);
+            if (total_key(a) >= total_key(l)) l = a;
+        }
+    }
+    if (!(l > 0.0)) {  // ZeroLpCoefficients (also NaN)
+        out->status = 3;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    // floor(log2(l)) as the host libm computes it: exponent, bumped when l sits in the
+    // (few-ulp) band below 2^(e+1) where log2() rounds up to e+1 (table built on the host)
+    int32_t fl;
+    if (isinf(l)) {
+        fl = INT32_MAX;
+    } else {
+        int e = ilogb(l);
+        fl = e;
+        if (e >= -64 && e < 64 && l >= p.log2_thr[e + 64]) {
+            fl = e + 1;
+            atomicAdd(&p.stats[2], 1u);
+        }
+    }
+    int32_t sh = (int32_t)((uint32_t)(int32_t)(precision - 1) - (uint32_t)fl - 1u);
+    if (sh > 15) sh = 15;
+    if (sh < -16) {  // LpNegativeShiftError
+        out->status = 4;
+        atomicAdd(&p.stats[0], 1u);
+        return;
+    }
+    double error = 0.0;
+    const double scale = (double)(1 << (sh >= 0 ? sh : -sh));
+#pragma unroll
+    for (int i = 0; i < LMAX; i++) {
+        if ((uint32_t)i >= order) continue;
+        double sum = sh >= 0 ? __builtin_fma(c[i], scale, error) : (c[i] / scale) + error;
+        double rr = round(sum);
+        int32_t q = (rr != rr) ? 0 : rr >= 2147483647.0 ? INT32_MAX : rr <= -2147483648.0 ? INT32_MIN
+                                                                                         : (int32_t)rr;
+        q = q < min_coeff ? min_coeff : q > max_coeff ? max_coeff : q;
+        error = sum - (double)q;
+        out->qlp[i] = q;
+    }
+    out->status = 0;
+    out->order = (uint8_t)order;
+    out->precision = (uint8_t)precision;
+    out->shift = (uint8_t)(sh >= 0 ? sh : 0);
+}
+
 // ---------------------------------------------------------------------------------
 // K5: LPC FIR residual + Rice search + fixed/LPC/verbatim choice, one workgroup per
 // (frame, candidate).  dynamic LDS: x[n] | r[n]
@@ -3928,6 +4084,13 @@ bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_fram
     return false;
 }
 
+void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st) {
+    if (p.max_lpc_order <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<8>), dim3(blocks), dim3(64), 0, st, p);
+    else if (p.max_lpc_order <= 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<12>), dim3(blocks), dim3(64), 0, st, p);
+    else if (p.max_lpc_order <= 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<16>), dim3(blocks), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
+}
+
 // block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
 #define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
 bool wave_block_size(uint32_t B) {
@@ -4295,7 +4458,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         if (full) dispatch_autocorr(H, p, 0, full, B, c->d_window_full, st);
         if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
         begin(4);
-        hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, p);
+        launch_lpc(p, (ncb + 63) / 64, st);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         begin(5);
         if (pf.fcount && !w64) {
@@ -4540,7 +4703,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits);
         if (lpc) {
             dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
-            hipLaunchKernelGGL(k_lpc, dim3((ncb + 63) / 64), dim3(64), 0, st, r);
+            launch_lpc(r, (ncb + 63) / 64, st);
         }
         launch_cand64(r, B, (ncb + 3) / 4, st);
         hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
