@@ -1535,10 +1535,11 @@ __device__ __forceinline__ void levinson_u(const double (&acr)[LMAX + 1], uint32
     }
 }
 
-// K4 with max_lpc_order <= LMAX <= 16 known at compile time: with run-time loop bounds the
+// K4 with max_lpc_order <= LMAX known at compile time: with run-time loop bounds the
 // coefficient arrays sit in scratch memory and every access is a memory round trip
 template <int LMAX>
 __global__ void __launch_bounds__(64) k_lpc_u(Params p) {
+    static_assert(LMAX <= FLACGPU_MAX_LPC_ORDER, "order");
     const uint32_t idx = p.f0 * p.ncand + blockIdx.x * 64 + threadIdx.x;
     if (idx >= (p.f0 + p.fcount) * p.ncand) return;
     const uint32_t frame = idx / p.ncand;
@@ -2311,7 +2312,7 @@ __device__ __forceinline__ WaveRice wave_rice(Src src, uint32_t order, const Par
 }
 
 // FIR of one lane's 64 samples, IN PLACE and descending (x[e] is dead once its residual exists);
-// hp[16] = the 16 samples before them (zeros for lane 0); coefficients are wave-uniform.
+// hp[MAXO] = the MAXO samples before them (zeros for lane 0); coefficients are wave-uniform.
 // Returns the sign-bit OR of every i32 subtraction overflow outside the warm-up
 // (ResidualOverflow, encode.rs:3190-3197).
 struct KeepResidual {  // fir64 consumer: just store the residual
@@ -2319,14 +2320,14 @@ struct KeepResidual {  // fir64 consumer: just store the residual
 };
 // f(e, residual) -> value stored in x[e]: lets a caller consume each residual where it is
 // produced (k_frame64 sums the code lengths there)
-template <int T, int SPL, int CBASE = 2, class F = KeepResidual>
-__device__ __forceinline__ uint32_t fir64(int32_t (&x)[SPL], const int32_t (&hp)[16], uint32_t lpw,
+template <int T, int SPL, int MAXO = 16, int CBASE = 2, class F = KeepResidual>
+__device__ __forceinline__ uint32_t fir64(int32_t (&x)[SPL], const int32_t (&hp)[MAXO], uint32_t lpw,
                                           uint32_t order, uint32_t shift, F &&f = F()) {
     int32_t c[T];  // wave-uniform (SGPRs): coefficient j was loaded by lane CBASE + j
 #pragma unroll
     for (int j = 0; j < T; j++) c[j] = (uint32_t)j < order ? (int32_t)sread(lpw, CBASE + j) : 0;
     // bit e set: sample e of this lane is warm-up (lane 0 only)
-    const uint32_t warm = (threadIdx.x & 63) == 0 ? ((1u << order) - 1u) : 0u;
+    const uint32_t warm = (threadIdx.x & 63) == 0 ? (order >= 32 ? 0xFFFFFFFFu : (1u << order) - 1u) : 0u;
     uint32_t ovf = 0;
 #pragma unroll
     for (int e = SPL - 1; e >= 0; e--) {
@@ -2334,13 +2335,13 @@ __device__ __forceinline__ uint32_t fir64(int32_t (&x)[SPL], const int32_t (&hp)
 #pragma unroll
         for (int j = 0; j < T; j++) {
             const int i = e - 1 - j;
-            const int32_t v = i >= 0 ? x[i >= 0 ? i : 0] : hp[i >= 0 ? 0 : 16 + i];
+            const int32_t v = i >= 0 ? x[i >= 0 ? i : 0] : hp[i >= 0 ? 0 : MAXO + i];
             sum += (long long)v * (long long)c[j];
         }
         const int32_t pred = (int32_t)(sum >> shift);
         const int32_t d = (int32_t)((uint32_t)x[e] - (uint32_t)pred);
         uint32_t o = (uint32_t)(x[e] ^ pred) & (uint32_t)(x[e] ^ d);  // sign bit: x - pred overflowed
-        if (e < 16) o &= ~(warm << (31 - e));
+        if (e < MAXO) o &= ~(warm << (31 - e));
         ovf |= o;
         x[e] = f(e, d);
         if ((e & 3) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -2395,8 +2396,9 @@ __device__ __forceinline__ void load_lane(const int32_t *row, uint32_t lane, int
     }
 }
 
-template <int SPL>
+template <int SPL, int MAXO>
 __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
+    static_assert(MAXO <= SPL && (MAXO == 16 || MAXO == 32), "history comes from the previous lane only");
     constexpr uint32_t N = 64u * SPL;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2512,20 +2514,32 @@ __global__ void __launch_bounds__(WG, 2) k_cand64(Params p) {
     uint32_t lorder = 0;
     if (lstatus == 0) {
         lorder = lmeta & 0xFF;
-        int32_t hp[16];
+        int32_t hp[MAXO];
 #pragma unroll
-        for (int k = 0; k < 16; k++) hp[k] = lane_prev(x[SPL - 16 + k]);
+        for (int k = 0; k < MAXO; k++) hp[k] = lane_prev(x[SPL - MAXO + k]);
         uint32_t ovf;
         switch ((lorder + 3) >> 2) {
-        case 1: ovf = fir64<4, SPL>(x, hp, lpw, lorder, lshift); break;
-        case 2: ovf = fir64<8, SPL>(x, hp, lpw, lorder, lshift); break;
-        case 3: ovf = fir64<12, SPL>(x, hp, lpw, lorder, lshift); break;
-        default: ovf = fir64<16, SPL>(x, hp, lpw, lorder, lshift); break;
+        case 1: ovf = fir64<4, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+        case 2: ovf = fir64<8, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+        case 3: ovf = fir64<12, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+        case 4: ovf = fir64<16, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+        default:
+            if constexpr (MAXO == 32) {
+                switch ((lorder + 3) >> 2) {
+                case 5: ovf = fir64<20, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+                case 6: ovf = fir64<24, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+                case 7: ovf = fir64<28, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+                default: ovf = fir64<32, SPL, MAXO>(x, hp, lpw, lorder, lshift); break;
+                }
+            } else {
+                ovf = fir64<16, SPL, MAXO>(x, hp, lpw, lorder, lshift);
+            }
+            break;
         }
         if (__any(ovf)) {
             if (lane == 0) atomicAdd(&p.stats[0], 1u);
         } else {
-            lw = wave_rice<SPL, 16>(StoredSrc<SPL>{x}, lorder, p);
+            lw = wave_rice<SPL, MAXO>(StoredSrc<SPL>{x}, lorder, p);
             lpc_ok = lw.ok;
             if (!lpc_ok && lane == 0) atomicAdd(&p.stats[0], 1u);
             lpc_bits = 8u + wasted + lorder * bps_eff + 4u + 5u + lorder * lprec + lw.bits;
@@ -3318,7 +3332,7 @@ struct BitRun {  // a lane's contiguous MSB-first bit run inside an LDS word arr
     }
 };
 
-template <int SPL>
+template <int SPL, int MAXO>
 __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, uint32_t ch,
                                               uint32_t *sb, uint32_t base) {
     const uint32_t lane = threadIdx.x & 63;
@@ -3397,7 +3411,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
     if (lane == 0) {
         br.init(sb, body0);
 #pragma unroll
-        for (int e = 0; e < 16; e++)
+        for (int e = 0; e < MAXO; e++)
             if ((uint32_t)e < order) br.put((uint32_t)x[e] & smask, bps);
         br.finish();
     }
@@ -3410,7 +3424,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         bool rice;
         __device__ __forceinline__ int32_t operator()(int e, int32_t r) {
             uint32_t u = zigzag(r);
-            if (e < 16) u = (uint32_t)e >= first ? u : 0u;
+            if (e < MAXO) u = (uint32_t)e >= first ? u : 0u;
             const uint32_t q = u >> ks;
             qsum += q;
             qmax = q > qmax ? q : qmax;
@@ -3425,14 +3439,26 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         }
         if (lane >= 6 && lane < 6 + order) lds_put(sb, resid_pos + 9 + (lane - 6) * prec, cw, prec);
         resid_pos += 9 + order * prec;
-        int32_t hp[16];
+        int32_t hp[MAXO];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) hp[kk] = lane_prev(x[SPL - 16 + kk]);
+        for (int kk = 0; kk < MAXO; kk++) hp[kk] = lane_prev(x[SPL - MAXO + kk]);
         switch ((order + 3) >> 2) {  // the residual, in place (encode.rs:3181-3197)
-        case 1: fir64<4, SPL, 6>(x, hp, cw, order, shift, len); break;
-        case 2: fir64<8, SPL, 6>(x, hp, cw, order, shift, len); break;
-        case 3: fir64<12, SPL, 6>(x, hp, cw, order, shift, len); break;
-        default: fir64<16, SPL, 6>(x, hp, cw, order, shift, len); break;
+        case 1: fir64<4, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+        case 2: fir64<8, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+        case 3: fir64<12, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+        case 4: fir64<16, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+        default:
+            if constexpr (MAXO == 32) {
+                switch ((order + 3) >> 2) {
+                case 5: fir64<20, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+                case 6: fir64<24, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+                case 7: fir64<28, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+                default: fir64<32, SPL, MAXO, 6>(x, hp, cw, order, shift, len); break;
+                }
+            } else {
+                fir64<16, SPL, MAXO, 6>(x, hp, cw, order, shift, len);
+            }
+            break;
         }
     } else {  // FIXED: iterated differences in place (encode.rs:3039-3060)
         int32_t h[4];
@@ -3473,7 +3499,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
             const uint32_t u = (uint32_t)x[e];
             uint32_t nb = (u >> k) + k1;
             uint32_t v = stop | (u & lowmask);
-            if (e < 16) {  // warm-up samples of lane 0 carry no residual
+            if (e < MAXO) {  // warm-up samples of lane 0 carry no residual
                 nb = (uint32_t)e >= first ? nb : 0u;
                 v = (uint32_t)e >= first ? v : 0u;
             }
@@ -3484,7 +3510,7 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         const uint32_t stop = 1u << k, lowmask = stop - 1u;
 #pragma unroll
         for (int e = 0; e < SPL; e++) {
-            if (e >= 16 || (uint32_t)e >= first) {
+            if (e >= MAXO || (uint32_t)e >= first) {
                 const uint32_t u = (uint32_t)x[e];
                 uint32_t qn = u >> k;
                 const uint32_t v = stop | (u & lowmask);
@@ -3502,12 +3528,12 @@ __device__ __forceinline__ void wave_subframe(const Params &p, uint32_t frame, u
         const uint32_t emask = eb >= 32 ? 0xFFFFFFFFu : (1u << eb) - 1u;
 #pragma unroll
         for (int e = 0; e < SPL; e++)
-            if (e >= 16 || (uint32_t)e >= first) br.put((uint32_t)x[e] & emask, eb);
+            if (e >= MAXO || (uint32_t)e >= first) br.put((uint32_t)x[e] & emask, eb);
     }
     br.finish();
 }
 
-template <int NT, int SPL>
+template <int NT, int SPL, int MAXO>
 __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     constexpr uint32_t N = 64u * SPL;
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -3558,7 +3584,7 @@ __global__ void __launch_bounds__(NT, 2) k_frame64(Params p, PackParams q) {
     }
     uint32_t start_bit = header_bytes(hc) * 8;
     for (uint32_t c = 0; c < ch; c++) start_bit += p.out_plan[(size_t)frame * p.channels + c].bits;
-    if (!(p.dbg & 2)) wave_subframe<SPL>(p, frame, ch, fb, start_bit);
+    if (!(p.dbg & 2)) wave_subframe<SPL, MAXO>(p, frame, ch, fb, start_bit);
     __syncthreads();
     // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4)).
     // One pass: the frame, left-padded with zero bytes (they leave a zero CRC state unchanged) to
@@ -4088,7 +4114,8 @@ void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st) {
     if (p.max_lpc_order <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<8>), dim3(blocks), dim3(64), 0, st, p);
     else if (p.max_lpc_order <= 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<12>), dim3(blocks), dim3(64), 0, st, p);
     else if (p.max_lpc_order <= 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<16>), dim3(blocks), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
+    else if (getenv("FLACGPU_LPC_DYN")) hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<32>), dim3(blocks), dim3(64), 0, st, p);
 }
 
 // block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
@@ -4103,22 +4130,26 @@ bool wave_block_size(uint32_t B) {
     }
 }
 void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+    if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks only
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 32>), dim3(blocks), dim3(WG), 0, st, p);
+        return;
+    }
     switch (B) {
-#define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl>), dim3(blocks), dim3(WG), 0, st, p); break;
+#define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl, 16>), dim3(blocks), dim3(WG), 0, st, p); break;
         FLACGPU_WAVE_SIZES(X)
 #undef X
     default: break;
     }
 }
-template <int NT, int SPL>
+template <int NT, int SPL, int MAXO = 16>
 void launch_frame64_nt(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
     static bool big_lds = false;  // frames of 5..8 channels need more than the default 64 KB
     if (lds > 64 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute((const void *)k_frame64<NT, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   150 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_frame64<NT, SPL, MAXO>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         big_lds = true;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<NT, SPL>), dim3(frames), dim3(NT), lds, st, p, q);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<NT, SPL, MAXO>), dim3(frames), dim3(NT), lds, st, p, q);
 }
 template <int SPL>
 void launch_frame64_spl(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
@@ -4140,6 +4171,15 @@ void launch_frame64_spl(const Params &p, const PackParams &q, uint32_t frames, s
     }
 }
 void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
+    if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks, <= 4 channels
+        switch (p.channels) {
+        case 1: launch_frame64_nt<64, 64, 32>(p, q, frames, lds, st); break;
+        case 2: launch_frame64_nt<128, 64, 32>(p, q, frames, lds, st); break;
+        case 3: launch_frame64_nt<192, 64, 32>(p, q, frames, lds, st); break;
+        default: launch_frame64_nt<256, 64, 32>(p, q, frames, lds, st); break;
+        }
+        return;
+    }
     switch (B) {
 #define X(n, spl) case n: launch_frame64_spl<spl>(p, q, frames, lds, st); break;
         FLACGPU_WAVE_SIZES(X)
@@ -4428,7 +4468,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
     // wave-per-candidate kernel (FIXED + LPC analysis of a candidate in one wave, after the LPC
     // parameters are known): block lengths 64 x {16, 18, 32, 36, 64}, LPC order <= 16
-    const bool w64 = narrow && wave_block_size(B) && p.max_lpc_order <= 16 && p.max_po <= 6 &&
+    const bool w64 = narrow && wave_block_size(B) && (p.max_lpc_order <= 16 || B == FN) && p.max_po <= 6 &&
                      !getenv("FLACGPU_NO_W64");
     const bool fast16 = narrow && B == FN;  // 16-samples-per-lane register kernels (any order)
     const uint32_t n_fast = (w64 || fast16) ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
@@ -4572,7 +4612,8 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
     const size_t lds_frame = ((size_t)fbw + WG * 20) * sizeof(int32_t);
     // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}, order <= 16, <= 4 channels
-    const bool f64w = narrow && wave_block_size(B) && p.max_lpc_order <= 16 &&
+    const bool f64w = narrow && wave_block_size(B) &&
+                      (p.max_lpc_order <= 16 || (B == FN && p.channels <= 4)) &&
                       (p.channels <= 4 || B == FN) && p.max_po <= 6 &&
                       (size_t)fbw * sizeof(int32_t) <= 150 * 1024 &&
                       !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64");
@@ -4660,7 +4701,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     const uint32_t fbw = frame_fb_words(c->channels, c->bps, B);
     const bool eligible =
         d_pcm && n_frames >= 256 && n_frames <= c->max_frames && last_len == B && wave_block_size(B) &&
-        (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && c->opts.max_lpc_order <= 16 &&
+        (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
+        (c->opts.max_lpc_order <= 16 || (B == FN && c->channels <= 4)) &&
         c->opts.max_partition_order <= 6 && (c->channels <= 4 || B == FN) && (layout == 0 || layout == 1) &&
         (size_t)fbw * sizeof(int32_t) <= 150 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
         !getenv("FLACGPU_NO_W64") && !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64") &&
