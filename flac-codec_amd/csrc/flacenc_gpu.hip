@@ -1024,10 +1024,12 @@ __device__ __forceinline__ void ac3_tile(Ac3Lane<ROWS> &L, int32_t *tile, uint32
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int A, int LG, bool STEREO>
-__device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][BUF] */,
-                                         uint32_t frame0, uint32_t nframes, uint32_t n,
-                                         const double *__restrict__ win, uint32_t group) {
+// per-lane constants of a wave: which candidate, which staged rows, where to stage from
+template <bool STEREO>
+__device__ __forceinline__ bool ac3_setup(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                                          const double *__restrict__ win, uint32_t group,
+                                          Ac3Lane<STEREO ? 32 : 64> &L, uint32_t &frame_out,
+                                          uint32_t &cand_out) {
     constexpr int ROWS = STEREO ? 32 : 64;
     constexpr int AC3_RAW = Ac3Lane<ROWS>::RAW;
     const uint32_t lane = threadIdx.x & 63;
@@ -1036,9 +1038,10 @@ __device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][B
     const bool live = cand0 + lane < total;
     const uint32_t cc = live ? cand0 + lane : total - 1;  // clamped: results of dead lanes are dropped
     const uint32_t frame = frame0 + cc / p.ncand, cand = cc % p.ncand;
+    frame_out = frame;
+    cand_out = cand;
     const CandInfo ci = p.cinfo[(size_t)frame * p.ncand + cand];
     const uint32_t wasted = (ci.active && !ci.is_const) ? ci.wasted : 0;
-    Ac3Lane<ROWS> L;
     const uint32_t srow = lane >> 3, scol = (lane & 7) * 4;
     if constexpr (STEREO) {
         // candidate = (a + cb * b) >> sh over the frame's rows L (2 fl) and R (2 fl + 1)
@@ -1073,6 +1076,18 @@ __device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][B
     // the window slice (32 f64) is staged by every group of 16 lanes (identical data, same addresses)
     L.wsrc = win + 2 * (lane & 15);
     L.wdst = AC3_RAW + 4 * (lane & 15);
+    return live;
+}
+
+template <int A, int LG, bool STEREO>
+__device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][BUF] */,
+                                         uint32_t frame0, uint32_t nframes, uint32_t n,
+                                         const double *__restrict__ win, uint32_t group) {
+    constexpr int ROWS = STEREO ? 32 : 64;
+    constexpr int AC3_RAW = Ac3Lane<ROWS>::RAW;
+    Ac3Lane<ROWS> L;
+    uint32_t frame, cand;
+    const bool live = ac3_setup<STEREO>(p, frame0, nframes, n, win, group, L, frame, cand);
     double acc[LG];
 #pragma unroll
     for (int k = 0; k < LG; k++) acc[k] = -0.0;  // f64 `sum()` identity
@@ -1090,6 +1105,103 @@ __device__ __forceinline__ void ac3_wave(const Params &p, int32_t *tile /* [2][B
         double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
 #pragma unroll
         for (int k = 0; k < LG; k++) out[k] = acc[k];
+    }
+}
+
+// ---- lags up to 32 (LPC orders 17..32): the history of a 16-sample block is the TWO blocks before
+// it, so four f64 block buffers rotate (period: two tiles).  FIRST: 0 steady state, 1 / 2 the first /
+// second block of the frame (terms whose partner lies before the frame start are not formed).
+template <int A, int LG, int FIRST>
+__device__ __forceinline__ void ac3_block_deep(const double (&w)[16], const double (&p1)[16],
+                                               const double (&p2)[16], double (&acc)[LG]) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        double prod[LG];
+#pragma unroll
+        for (int k = 0; k < LG; k++) {
+            const int idx = s - (A + k);
+            const double o = idx >= 0 ? w[idx >= 0 ? idx : 0]
+                           : idx >= -16 ? p1[(idx < 0 && idx >= -16) ? 16 + idx : 0]
+                                        : p2[(idx < -16) ? 32 + idx : 0];
+            prod[k] = w[s] * o;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < LG; k++) {
+            const int lag = A + k;
+            if (FIRST == 1 && s < lag) continue;
+            if (FIRST == 2 && 16 + s < lag) continue;
+            acc[k] = acc[k] + prod[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one tile (two blocks): X0, X1 receive the tile's blocks; Y0, Y1 hold the previous tile's
+template <int A, int LG, bool FIRSTT, int ROWS>
+__device__ __forceinline__ void ac3_tile_deep(Ac3Lane<ROWS> &L, int32_t *tile, uint32_t t, Ac3Raw &raw,
+                                              double (&X0)[16], double (&X1)[16], double (&Y0)[16],
+                                              double (&Y1)[16], double (&acc)[LG]) {
+    const uint32_t buf = t & 1;
+    constexpr int AC3_RAW = Ac3Lane<ROWS>::RAW, AC3_BUF = Ac3Lane<ROWS>::BUF;
+    int32_t *cur = tile + buf * AC3_BUF, *nxt = tile + (buf ^ 1) * AC3_BUF;
+    ac3_load(cur + L.off_a, cur + L.off_b, reinterpret_cast<const double *>(cur + AC3_RAW), 0, raw);
+    ac3_convert(raw, L.cb, L.sh, X0);
+    ac3_block_deep<A, LG, FIRSTT ? 1 : 0>(X0, Y1, Y0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    ac3_load(cur + L.off_a, cur + L.off_b, reinterpret_cast<const double *>(cur + AC3_RAW), 16, raw);
+    ac3_commit(L, nxt);   // tile t+1, fetched one whole tile ago
+    ac3_sync();
+    ac3_fetch(L, t + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    ac3_convert(raw, L.cb, L.sh, X1);
+    ac3_block_deep<A, LG, FIRSTT ? 2 : 0>(X1, X0, Y1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int A, int LG, bool STEREO>
+__device__ __forceinline__ void ac3_wave_deep(const Params &p, int32_t *tile, uint32_t frame0,
+                                              uint32_t nframes, uint32_t n,
+                                              const double *__restrict__ win, uint32_t group) {
+    constexpr int ROWS = STEREO ? 32 : 64;
+    Ac3Lane<ROWS> L;
+    uint32_t frame, cand;
+    const bool live = ac3_setup<STEREO>(p, frame0, nframes, n, win, group, L, frame, cand);
+    double acc[LG];
+#pragma unroll
+    for (int k = 0; k < LG; k++) acc[k] = -0.0;  // f64 `sum()` identity
+    double wa[16], wb[16], wc[16], wd[16];
+    Ac3Raw raw;
+    ac3_fetch(L, 0);
+    ac3_commit(L, tile);
+    ac3_sync();
+    ac3_fetch(L, 1);
+    ac3_tile_deep<A, LG, true>(L, tile, 0, raw, wa, wb, wc, wd, acc);
+    uint32_t t = 1;
+#pragma unroll 1
+    for (; t + 1 < L.ntiles; t += 2) {  // n is a multiple of 64: an even number of tiles
+        ac3_tile_deep<A, LG, false>(L, tile, t, raw, wc, wd, wa, wb, acc);
+        ac3_tile_deep<A, LG, false>(L, tile, t + 1, raw, wa, wb, wc, wd, acc);
+    }
+    if (t < L.ntiles) ac3_tile_deep<A, LG, false>(L, tile, t, raw, wc, wd, wa, wb, acc);
+    if (live) {
+        double *out = p.ac + ((size_t)frame * p.ncand + cand) * AC_LD + A;
+#pragma unroll
+        for (int k = 0; k < LG; k++) out[k] = acc[k];
+    }
+}
+
+template <bool STEREO>
+__global__ void __launch_bounds__(256)
+k_autocorr3_deep(Params p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *__restrict__ win) {
+    __shared__ __attribute__((aligned(16))) int32_t tiles[4][2 * Ac3Lane<STEREO ? 32 : 64>::BUF];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int32_t *tile = tiles[wave];
+    switch (wave) {  // 33 lags: 8 + 8 + 8 + 9
+    case 0: ac3_wave_deep<0, 8, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+    case 1: ac3_wave_deep<8, 8, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+    case 2: ac3_wave_deep<16, 8, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
+    default: ac3_wave_deep<24, 9, STEREO>(p, tile, frame0, nframes, n, win, blockIdx.x); break;
     }
 }
 
@@ -4217,16 +4329,24 @@ void launch_autocorr3_nl(const Params &p, uint32_t frame0, uint32_t nframes, uin
 // samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
 bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
                    hipStream_t st) {
-    if (n < 32 || n % 32 != 0 || p.max_lpc_order > 16 || getenv("FLACGPU_NO_AC3")) return false;
-    if (p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24) {
-        launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
+    if (n < 32 || n % 32 != 0 || getenv("FLACGPU_NO_AC3")) return false;
+    const bool stereo = p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24;
+    const bool indep = !p.stereo4 && p.ncand == p.channels;
+    if (!stereo && !indep) return false;
+    if (p.max_lpc_order > 16) {  // lags up to 32: two blocks of history, frame a multiple of 64
+        if (n % 64 != 0) return false;
+        const uint32_t groups = (nframes * p.ncand + 63) / 64;
+        if (stereo)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                               nframes, n, win);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
+                               nframes, n, win);
         return true;
     }
-    if (!p.stereo4 && p.ncand == p.channels) {
-        launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
-        return true;
-    }
-    return false;
+    if (stereo) launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
+    else launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
+    return true;
 }
 
 template <int H>
