@@ -455,46 +455,7 @@ __device__ bool rice_search(const int32_t *r, uint32_t n, uint32_t order, const 
     return rice_finish(S, pk, n, mine, plan, resid_bits);
 }
 
-// Fast path: block of exactly 4096 samples, lane t holds the residuals of samples
-// [16 t, 16 t + 16) in registers (v[e] valid for 16 t + e >= order).  Same decisions as
-// rice_search, no residual array in LDS.
-constexpr uint32_t FN = 4096;
-__device__ bool rice16(const int32_t (&v)[16], uint32_t order, const Params &p, RiceShared &S,
-                       SubPlan &plan /* LDS */, uint32_t &resid_bits) {
-    const uint32_t tid = threadIdx.x;
-    const uint32_t P = rice_levels(FN, p);
-    const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
-    // precondition: rice_init(S) was called and a barrier passed since (the kernels do it
-    // ahead of their first workgroup reduction)
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-        if ((uint32_t)e >= first) acc += uabs(v[e]);
-    atomicAdd(&S.leaf[(16 * tid) >> (12 - P)], acc);  // leaf length = 4096 >> P >= 64
-    __syncthreads();
-    rice_tree(S, FN, order, P, p.use_rice2 ? 31u : 15u);
-    const RicePick pk = rice_pick(S, P, p.use_rice2);
-    unsigned long long mine = 0;
-    if (pk.bp >= 0) {
-        mine += rice_partition_fixed_bits(S, pk, plan);
-        const uint32_t k = S.nd_rice[(1u << pk.bp) + ((16 * tid) >> (12 - pk.bp))];
-        if (k != 0xFF) {
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-                if ((uint32_t)e >= first) mine += zigzag(v[e]) >> k;
-        }
-    } else {
-        if (tid == 0) {
-            plan.rice[0] = 0xFF;
-            plan.escape_bits[0] = 31;
-            mine += 4u + 5u + 31u * (FN - order);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            if ((uint32_t)e >= first && (v[e] < -(1 << 30) || v[e] >= (1 << 30))) mine |= 1ull << 52;
-    }
-    return rice_finish(S, pk, FN, mine, plan, resid_bits);
-}
+constexpr uint32_t FN = 4096;  // the block length of every preset but `fast`
 
 __device__ __forceinline__ void plan_clear(SubPlan &plan) {
     uint32_t *w = reinterpret_cast<uint32_t *>(&plan);
@@ -1364,7 +1325,7 @@ __device__ __forceinline__ void ac_wave(const Params &p, int32_t (*tile)[AC_MAXR
 }
 
 #ifndef AC_TILE
-#define AC_TILE 64   // samples per LDS tile (32 + a 128-VGPR cap overlapped better with k_fixed16
+#define AC_TILE 64   // samples per LDS tile (32 + a 128-VGPR cap overlapped better with other kernels
                      // but ran 0.55 instead of 0.35 ms on its own: net loss)
 #endif
 template <int H, int NW>
@@ -1863,315 +1824,12 @@ __global__ void __launch_bounds__(WG) k_fir(Params p) {
 }
 
 // =================================================================================
-// Fast path for blocks of exactly 4096 samples (the default block size of every preset but
-// `fast`): lane t of the 256-thread workgroup owns samples [16 t, 16 t + 16) IN REGISTERS;
-// all per-sample loops are statically unrolled, neighbours come through a small LDS halo, no
-// per-block arrays live in LDS (occupancy is register-bound).  Decisions are identical to the
-// generic kernels (same helpers).  Requires candidate bps <= 25 (biased-unsigned difference
-// arithmetic, see k_fixed16); the generic kernels handle wider input.
-// =================================================================================
-__device__ __forceinline__ void load_cand16(const CandSrc &src, uint32_t t, int32_t (&x)[16]) {
-    const int4 *pa = reinterpret_cast<const int4 *>(src.a) + 4 * t;
-    int4 a[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) a[q] = pa[q];
-    if (src.mode == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            x[4 * q] = a[q].x; x[4 * q + 1] = a[q].y; x[4 * q + 2] = a[q].z; x[4 * q + 3] = a[q].w;
-        }
-    } else {
-        const int4 *pb = reinterpret_cast<const int4 *>(src.b) + 4 * t;
-        int4 b[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) b[q] = pb[q];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            x[4 * q] = combine(src.mode, a[q].x, b[q].x);
-            x[4 * q + 1] = combine(src.mode, a[q].y, b[q].y);
-            x[4 * q + 2] = combine(src.mode, a[q].z, b[q].z);
-            x[4 * q + 3] = combine(src.mode, a[q].w, b[q].w);
-        }
-    }
-}
-
-// five u64 sums over the workgroup with one barrier pair; scratch holds 4 * 5 u64
-__device__ __forceinline__ void block_sum5(uint64_t (&v)[5], uint64_t *scratch) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = wave_sum_u64(v[k]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) scratch[(threadIdx.x >> 6) * 5 + k] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = scratch[k] + scratch[5 + k] + scratch[10 + k] + scratch[15 + k];
-}
-
-__global__ void __launch_bounds__(WG, 4) k_fixed16(Params p) {
-    __shared__ RiceShared RS;
-    __shared__ SubPlan plan;
-    __shared__ uint64_t red[20];
-    __shared__ int4 halo[WG];
-
-    uint32_t frame, cand;
-    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
-    frame += p.f0;
-    const uint32_t n = FN;
-    const size_t cidx = (size_t)frame * p.ncand + cand;
-    const uint32_t tid = threadIdx.x;
-    const CandInfo ci = p.cinfo[cidx];  // written by k_candinfo (wasted bits, activity)
-    if (!ci.active) return;
-    const CandSrc src = cand_src(p, frame, cand);
-    int32_t x[16];
-    load_cand16(src, tid, x);
-    rice_init(RS);
-    plan_clear(plan);
-    const uint32_t wasted = ci.is_const ? 32u : ci.wasted;  // encode.rs:2878-2898
-    if (wasted == 32u) {
-        __syncthreads();
-        if (tid == 0) {
-            plan.type = FLACGPU_SUB_CONSTANT;
-            plan.bps = (uint8_t)src.bps;
-            plan.source = src.source;
-            plan.bits = 8u + src.bps;
-        }
-        __syncthreads();
-        plan_store(p.fixed_plan + cidx, plan);
-        plan_store(p.cand_plan + cidx, plan);
-        return;
-    }
-    const uint32_t bps_eff = src.bps - wasted;
-#pragma unroll
-    for (int e = 0; e < 16; e++) x[e] >>= wasted;
-    halo[tid] = make_int4(x[12], x[13], x[14], x[15]);
-    __syncthreads();
-    int32_t q[20];
-    {
-        const int4 h = tid ? halo[tid - 1] : make_int4(0, 0, 0, 0);
-        q[0] = h.x; q[1] = h.y; q[2] = h.z; q[3] = h.w;
-#pragma unroll
-        for (int e = 0; e < 16; e++) q[4 + e] = x[e];
-    }
-    // residuals of orders 1..4 by iterated first differences (encode.rs:3039-3060) and their
-    // abs sums over [4, n) (:3062-3073).  Candidates here are <= 25 bits wide, so |d4| < 2^28:
-    // values are kept biased by 2^30 as unsigned, |a - b| + acc is one v_sad_u32, and two u32
-    // accumulators per order (8 terms each) cannot overflow.
-    constexpr uint32_t BIAS = 1u << 30;
-    uint32_t b0[20], b1[19], b2[18], b3[17];
-#pragma unroll
-    for (int i = 0; i < 20; i++) b0[i] = (uint32_t)q[i] + BIAS;
-#pragma unroll
-    for (int i = 0; i < 19; i++) b1[i] = b0[i + 1] - b0[i] + BIAS;   // d1 at sample 16t-3+i
-#pragma unroll
-    for (int i = 0; i < 18; i++) b2[i] = b1[i + 1] - b1[i] + BIAS;   // d2 at sample 16t-2+i
-#pragma unroll
-    for (int i = 0; i < 17; i++) b3[i] = b2[i + 1] - b2[i] + BIAS;   // d3 at sample 16t-1+i
-    uint32_t a0[2] = {0, 0}, a1[2] = {0, 0}, a2[2] = {0, 0}, a3[2] = {0, 0}, a4[2] = {0, 0};
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        if (tid > 0 || e >= 4) {
-            a0[e & 1] = __usad(b0[e + 4], BIAS, a0[e & 1]);
-            a1[e & 1] = __usad(b0[e + 4], b0[e + 3], a1[e & 1]);
-            a2[e & 1] = __usad(b1[e + 3], b1[e + 2], a2[e & 1]);
-            a3[e & 1] = __usad(b2[e + 2], b2[e + 1], a3[e & 1]);
-            a4[e & 1] = __usad(b3[e + 1], b3[e], a4[e & 1]);
-        }
-    }
-    uint64_t sm[5] = {(uint64_t)a0[0] + a0[1], (uint64_t)a1[0] + a1[1], (uint64_t)a2[0] + a2[1],
-                      (uint64_t)a3[0] + a3[1], (uint64_t)a4[0] + a4[1]};
-    block_sum5(sm, red);
-    uint32_t order = 0;
-#pragma unroll
-    for (uint32_t k = 1; k <= 4; k++)
-        if (sm[k] < sm[order]) order = k;  // min_by_key: first minimum wins
-    int32_t res[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++)
-        res[e] = order == 0 ? (int32_t)(b0[e + 4] - BIAS)
-               : order == 1 ? (int32_t)(b1[e + 3] - BIAS)
-               : order == 2 ? (int32_t)(b2[e + 2] - BIAS)
-               : order == 3 ? (int32_t)(b3[e + 1] - BIAS)
-                            : (int32_t)(b3[e + 1] - b3[e]);
-    uint32_t rbits = 0;
-    const bool fixed_ok = (p.dbg & 1) ? true : rice16(res, order, p, RS, plan, rbits);
-    if (tid == 0) {
-        plan.reserved[0] = fixed_ok ? 0 : 1;
-        plan.type = FLACGPU_SUB_FIXED;
-        plan.wasted = (uint8_t)wasted;
-        plan.bps = (uint8_t)bps_eff;
-        plan.order = (uint8_t)order;
-        plan.source = src.source;
-        plan.bits = 8u + wasted + order * bps_eff + rbits;
-    }
-    __syncthreads();
-    plan_store(p.fixed_plan + cidx, plan);
-    if (p.max_lpc_order == 0) {
-        __syncthreads();
-        const bool verbatim = !fixed_ok || !(plan.bits < n * bps_eff);
-        __syncthreads();
-        if (verbatim) plan_clear(plan);
-        __syncthreads();
-        if (tid == 0 && verbatim) make_verbatim(plan, n, bps_eff, wasted, src.source);
-        __syncthreads();
-        plan_store(p.cand_plan + cidx, plan);
-    }
-}
-
-// FIR over a register window: the PW-16 samples before this lane's run followed by its own 16
-// samples; T taps (order rounded up to 4, missing coefficients are zero)
-template <int T, int PW>
-__device__ __forceinline__ uint32_t fir16(const int32_t (&pw)[PW], const int32_t *qlp /* LDS */,
-                                          uint32_t shift, uint32_t first, int32_t (&res)[16]) {
-    constexpr int O = PW - 16;  // index of this lane's first own sample in the window
-    int32_t c[T];
-#pragma unroll
-    for (int j = 0; j < T; j++) c[j] = qlp[j];
-    uint32_t ovf = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        long long sum = 0;
-#pragma unroll
-        for (int j = 0; j < T; j++) sum += (long long)pw[O + e - 1 - j] * (long long)c[j];
-        const int32_t pred = (int32_t)(sum >> shift);
-        const long long d = (long long)pw[O + e] - (long long)pred;
-        if ((e >= 16 || (uint32_t)e >= first) && (d < INT32_MIN || d > INT32_MAX)) ovf = 1;  // ResidualOverflow
-        res[e] = (int32_t)d;
-    }
-    return ovf;
-}
-
-// PREV = rows of 16 earlier samples a lane needs: 1 when every order <= 16, else 2
-template <int PREV>
-__global__ void __launch_bounds__(WG) k_fir16(Params p) {
-    __shared__ RiceShared RS;
-    __shared__ SubPlan plan;
-    __shared__ uint64_t red[4];
-    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
-    __shared__ __attribute__((aligned(16))) int32_t xs[WG * 20];  // 16 samples + 4 pad per lane
-
-    uint32_t frame, cand;
-    map_block(blockIdx.x, p.ncand, p.fcount, frame, cand);
-    frame += p.f0;
-    const uint32_t n = FN;
-    const size_t cidx = (size_t)frame * p.ncand + cand;
-    const uint32_t tid = threadIdx.x;
-    const CandInfo ci = p.cinfo[cidx];
-    if (!ci.active || ci.is_const) return;
-    const LpcParams *lp = p.lpc + cidx;
-    const CandSrc src = cand_src(p, frame, cand);
-    const uint32_t wasted = ci.wasted, bps_eff = ci.bps;
-    bool lpc_ok = lp->status == 0;
-    uint32_t lpc_bits = 0;
-    plan_clear(plan);
-    if (lpc_ok) {
-        const uint32_t order = lp->order, shift = lp->shift;
-        if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = tid < order ? lp->qlp[tid] : 0;
-        constexpr int PW = 16 * PREV + 16;
-        int32_t pw[PW];
-        {
-            int32_t x[16];
-            load_cand16(src, tid, x);
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                x[e] >>= wasted;
-                pw[16 * PREV + e] = x[e];
-            }
-            int4 *row = reinterpret_cast<int4 *>(xs + tid * 20);
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) row[qd] = make_int4(x[4 * qd], x[4 * qd + 1], x[4 * qd + 2], x[4 * qd + 3]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < PREV; rr++) {  // rows tid-PREV .. tid-1
-            const int srcrow = (int)tid - PREV + rr;
-            const int4 *row = reinterpret_cast<const int4 *>(xs + (srcrow < 0 ? 0 : srcrow) * 20);
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const int4 v = srcrow < 0 ? make_int4(0, 0, 0, 0) : row[qd];
-                pw[16 * rr + 4 * qd] = v.x; pw[16 * rr + 4 * qd + 1] = v.y;
-                pw[16 * rr + 4 * qd + 2] = v.z; pw[16 * rr + 4 * qd + 3] = v.w;
-            }
-        }
-        const uint32_t first = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
-        int32_t res[16];
-        uint32_t ovf;
-        if constexpr (PREV == 1) {
-            switch ((order + 3) >> 2) {  // encode_residuals, encode.rs:3181-3197
-            case 1: ovf = fir16<4, PW>(pw, qlp, shift, first, res); break;
-            case 2: ovf = fir16<8, PW>(pw, qlp, shift, first, res); break;
-            case 3: ovf = fir16<12, PW>(pw, qlp, shift, first, res); break;
-            default: ovf = fir16<16, PW>(pw, qlp, shift, first, res); break;
-            }
-        } else {
-            switch ((order + 3) >> 2) {
-            case 1: ovf = fir16<4, PW>(pw, qlp, shift, first, res); break;
-            case 2: ovf = fir16<8, PW>(pw, qlp, shift, first, res); break;
-            case 3: ovf = fir16<12, PW>(pw, qlp, shift, first, res); break;
-            case 4: ovf = fir16<16, PW>(pw, qlp, shift, first, res); break;
-            case 5: ovf = fir16<20, PW>(pw, qlp, shift, first, res); break;
-            case 6: ovf = fir16<24, PW>(pw, qlp, shift, first, res); break;
-            case 7: ovf = fir16<28, PW>(pw, qlp, shift, first, res); break;
-            default: ovf = fir16<32, PW>(pw, qlp, shift, first, res); break;
-            }
-        }
-        rice_init(RS);
-        ovf = block_or_u32(ovf, red);
-        if (ovf) {
-            lpc_ok = false;
-            if (tid == 0) atomicAdd(&p.stats[0], 1u);
-        } else {
-            uint32_t rbits = 0;
-            if (!(p.dbg & 1) && !rice16(res, order, p, RS, plan, rbits)) {
-                lpc_ok = false;
-                if (tid == 0) atomicAdd(&p.stats[0], 1u);
-            }
-            lpc_bits = 8u + wasted + order * bps_eff + 4u + 5u + order * lp->precision + rbits;
-        }
-    }
-    __syncthreads();
-    const SubPlan *fx = p.fixed_plan + cidx;
-    const uint32_t fixed_bits = fx->bits;
-    const bool fixed_ok = fx->reserved[0] == 0;
-    const bool use_lpc = lpc_ok && (!fixed_ok || lpc_bits < fixed_bits);  // encode.rs:2929-2945
-    const uint32_t best_bits = use_lpc ? lpc_bits : fixed_bits;
-    const bool verbatim = (!fixed_ok && !lpc_ok) || !(best_bits < n * bps_eff);  // :2971-2979
-    if (verbatim) {
-        __syncthreads();
-        plan_clear(plan);
-        __syncthreads();
-        if (tid == 0) make_verbatim(plan, n, bps_eff, wasted, src.source);
-        __syncthreads();
-        plan_store(p.cand_plan + cidx, plan);
-    } else if (use_lpc) {
-        if (tid == 0) {
-            plan.type = FLACGPU_SUB_LPC;
-            plan.wasted = (uint8_t)wasted;
-            plan.bps = (uint8_t)bps_eff;
-            plan.order = lp->order;
-            plan.precision = lp->precision;
-            plan.shift = lp->shift;
-            plan.source = src.source;
-            plan.bits = lpc_bits;
-        }
-        if (tid < FLACGPU_MAX_LPC_ORDER) plan.coeffs[tid] = qlp[tid];
-        __syncthreads();
-        plan_store(p.cand_plan + cidx, plan);
-    } else {
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(fx);
-        uint32_t *d = reinterpret_cast<uint32_t *>(p.cand_plan + cidx);
-        for (uint32_t i = tid; i < sizeof(SubPlan) / 4; i += WG) d[i] = s[i];
-    }
-}
-
-// =================================================================================
 // Wave-per-candidate kernel for blocks of exactly 4096 samples (candidates <= 25 bits, LPC
 // order <= 16): ONE wave64 does the whole FIXED + LPC analysis of one candidate.  Lane l owns
 // samples [64 l, 64 l + 64) in registers, which is exactly one finest Rice partition, so the
 // partition tree needs no atomics; neighbours come through wave shuffles; there is NO workgroup
 // barrier in the kernel (the 4 waves of a workgroup are the 4 candidates of a frame and share
-// L1/L2).  Same decisions as k_fixed16 + k_fir16 (same helpers), about 40 % fewer instructions.
+// L1/L2).  Same decisions as the generic k_fixed + k_fir (same helpers).
 // =================================================================================
 struct WaveRice {
     uint32_t bits;      // residual block bits (method + order + partitions)
@@ -2920,18 +2578,13 @@ __device__ __forceinline__ void lds_put(uint32_t *sb, uint32_t pos, uint32_t v, 
     }
 }
 
-// MODE 0: any block length, residual rows read from HBM (written by k_emit)
-// MODE 1: 4096-sample blocks, residual rows read from HBM into registers
-// MODE 2: 4096-sample blocks, residuals RECOMPUTED from the PCM in registers (k_emit not needed)
-// One subframe's bits written into the MSB-first LDS bit string `sb` (zeroed by the caller, which
+// Generic subframe writer (any block length): residual rows read from HBM (written by k_emit).
+// One subframe's bits are written into the MSB-first LDS bit string `sb` (zeroed by the caller, which
 // has NOT synchronised yet) starting at bit `base`; `with_header` also writes the frame header at
-// bit 0.  xs: WG x 20 ints of LDS scratch (MODE 2).  Ends WITHOUT a barrier.
-template <int MODE, int PREV>
+// bit 0.  Ends WITHOUT a barrier.
 __device__ __forceinline__ void pack_subframe(const Params &p, const PackParams &q, uint32_t frame,
                                               uint32_t ch, uint32_t n, uint32_t *sb, uint32_t base,
-                                              bool with_header, int32_t *xs, const HeaderCodes &hc,
-                                              uint64_t fn) {
-    constexpr bool FAST = MODE != 0;
+                                              bool with_header, const HeaderCodes &hc, uint64_t fn) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint8_t hdr[16];
     const uint32_t tid = threadIdx.x;
@@ -2940,85 +2593,8 @@ __device__ __forceinline__ void pack_subframe(const Params &p, const PackParams 
     // residual row: every lane reads its own contiguous run straight from HBM/L2 (twice:
     // lengths, then codes; the second pass hits L1/L2)
     const int32_t *__restrict__ r = p.residuals + ((size_t)frame * p.channels + ch) * p.block_size;
-    int32_t v16[16];  // FAST (n == 4096): this lane's residuals [16 tid, 16 tid + 16) in registers
-    // MODE 2 keeps the wasted-bit-shifted samples of the source candidate in LDS (20-dword rows)
-    __shared__ int32_t qlp[FLACGPU_MAX_LPC_ORDER];
-    auto rd = [&](uint32_t i) -> int32_t {
-        if constexpr (MODE == 2) return xs[(i >> 4) * 20 + (i & 15)];
-        else return r[i];
-    };
-    if constexpr (MODE == 1) {
-        const int4 *pr = reinterpret_cast<const int4 *>(r) + 4 * tid;
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-            const int4 t4 = pr[qd];
-            v16[4 * qd] = t4.x; v16[4 * qd + 1] = t4.y; v16[4 * qd + 2] = t4.z; v16[4 * qd + 3] = t4.w;
-        }
-    }
-    if constexpr (MODE == 2) {
-        uint32_t cand = sp->source;
-        if (p.stereo4) cand = cand == FLACGPU_SRC_MID ? 2u : cand == FLACGPU_SRC_SIDE ? 3u : cand;
-        const CandSrc src = cand_src(p, frame, cand);
-        load_cand16(src, tid, v16);
-#pragma unroll
-        for (int e = 0; e < 16; e++) v16[e] >>= wasted;
-        int4 *row = reinterpret_cast<int4 *>(xs + tid * 20);
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++) row[qd] = make_int4(v16[4 * qd], v16[4 * qd + 1], v16[4 * qd + 2], v16[4 * qd + 3]);
-        if (tid < FLACGPU_MAX_LPC_ORDER) qlp[tid] = (type == FLACGPU_SUB_LPC && tid < order) ? sp->coeffs[tid] : 0;
-    }
+    auto rd = [&](uint32_t i) -> int32_t { return r[i]; };
     __syncthreads();
-    if constexpr (MODE == 2) {
-        if (type == FLACGPU_SUB_LPC) {  // same FIR as k_fir16 (encode.rs:3181-3197)
-            constexpr int PW = 16 * PREV + 16;
-            int32_t pw[PW];
-#pragma unroll
-            for (int e = 0; e < 16; e++) pw[16 * PREV + e] = v16[e];
-#pragma unroll
-            for (int rr = 0; rr < PREV; rr++) {
-                const int srcrow = (int)tid - PREV + rr;
-                const int4 *prow = reinterpret_cast<const int4 *>(xs + (srcrow < 0 ? 0 : srcrow) * 20);
-#pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int4 t4 = srcrow < 0 ? make_int4(0, 0, 0, 0) : prow[qd];
-                    pw[16 * rr + 4 * qd] = t4.x; pw[16 * rr + 4 * qd + 1] = t4.y;
-                    pw[16 * rr + 4 * qd + 2] = t4.z; pw[16 * rr + 4 * qd + 3] = t4.w;
-                }
-            }
-            const uint32_t shift = sp->shift;
-            if constexpr (PREV == 1) {
-                switch ((order + 3) >> 2) {
-                case 1: fir16<4, PW>(pw, qlp, shift, 16, v16); break;
-                case 2: fir16<8, PW>(pw, qlp, shift, 16, v16); break;
-                case 3: fir16<12, PW>(pw, qlp, shift, 16, v16); break;
-                default: fir16<16, PW>(pw, qlp, shift, 16, v16); break;
-                }
-            } else {
-                switch ((order + 3) >> 2) {
-                case 1: fir16<4, PW>(pw, qlp, shift, 16, v16); break;
-                case 2: fir16<8, PW>(pw, qlp, shift, 16, v16); break;
-                case 3: fir16<12, PW>(pw, qlp, shift, 16, v16); break;
-                case 4: fir16<16, PW>(pw, qlp, shift, 16, v16); break;
-                case 5: fir16<20, PW>(pw, qlp, shift, 16, v16); break;
-                case 6: fir16<24, PW>(pw, qlp, shift, 16, v16); break;
-                case 7: fir16<28, PW>(pw, qlp, shift, 16, v16); break;
-                default: fir16<32, PW>(pw, qlp, shift, 16, v16); break;
-                }
-            }
-        } else if (type == FLACGPU_SUB_FIXED && order > 0) {  // iterated differences, encode.rs:3039-3060
-            int32_t qv[20];
-            const int4 h = tid ? *reinterpret_cast<const int4 *>(xs + (tid - 1) * 20 + 12) : make_int4(0, 0, 0, 0);
-            qv[0] = h.x; qv[1] = h.y; qv[2] = h.z; qv[3] = h.w;
-#pragma unroll
-            for (int e = 0; e < 16; e++) qv[4 + e] = v16[e];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int32_t x0 = qv[e + 4], x1 = qv[e + 3], x2 = qv[e + 2], x3 = qv[e + 1], x4 = qv[e];
-                v16[e] = order == 1 ? x0 - x1 : order == 2 ? x0 - 2 * x1 + x2
-                       : order == 3 ? x0 - 3 * x1 + 3 * x2 - x3 : x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
-            }
-        }
-    }
 
     if (tid == 0) {
         if (with_header) {  // FrameHeader::build, stream.rs:242-276 (+ CRC-8, :194-197)
@@ -3091,23 +2667,7 @@ __device__ __forceinline__ void pack_subframe(const Params &p, const PackParams 
         const uint32_t hi = (tid + 1) * ept < n ? (tid + 1) * ept : n;
         // pass 1: code lengths of this lane's residuals (+ partition headers)
         uint32_t mybits = 0;
-        // FAST: a lane's 16-sample run lies inside one partition (partition length % 16 == 0)
-        const uint32_t first16 = order > 16 * tid ? (order - 16 * tid > 16 ? 16u : order - 16 * tid) : 0u;
-        uint32_t fk = 0, feb = 0;
-        bool fhead = false;
-        if constexpr (FAST) {
-            if (first16 < 16) {
-                const uint32_t i0 = 16 * tid + first16;
-                const uint32_t pj = i0 / plen;
-                fk = sp->rice[pj - first_j];
-                feb = sp->escape_bits[pj - first_j];
-                fhead = i0 == (pj * plen > order ? pj * plen : order);
-                if (fhead) mybits += hb + (fk == 0xFF ? 5u : 0u);
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if ((uint32_t)e >= first16) mybits += (fk != 0xFF) ? (zigzag(v16[e]) >> fk) + 1u + fk : feb;
-            }
-        } else if (lo < hi) {
+        if (lo < hi) {
             uint32_t pj = lo / plen;                 // partition (block-aligned index)
             uint32_t bound = (pj + 1) * plen;
             uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
@@ -3136,28 +2696,7 @@ __device__ __forceinline__ void pack_subframe(const Params &p, const PackParams 
         uint32_t mypos = pos + v - mybits;
         for (uint32_t w = 0; w < (tid >> 6); w++) mypos += wave_tot[w];
         // pass 2: emit
-        if constexpr (FAST) {
-            if (first16 < 16) {
-                if (fhead) {
-                    if (fk != 0xFF) { lds_put(sb, mypos, fk, hb); mypos += hb; }
-                    else { lds_put(sb, mypos, esc_code, hb); lds_put(sb, mypos + hb, feb, 5); mypos += hb + 5; }
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    if ((uint32_t)e >= first16) {
-                        if (fk != 0xFF) {
-                            const uint32_t u = zigzag(v16[e]);
-                            mypos += u >> fk;  // unary zeros (buffer is pre-zeroed)
-                            lds_put(sb, mypos, (1u << fk) | (u & ((1u << fk) - 1u)), fk + 1);
-                            mypos += fk + 1;
-                        } else if (feb) {
-                            lds_put(sb, mypos, (uint32_t)v16[e], feb);
-                            mypos += feb;
-                        }
-                    }
-                }
-            }
-        } else if (lo < hi) {
+        if (lo < hi) {
             uint32_t pj = lo / plen;
             uint32_t bound = (pj + 1) * plen;
             uint32_t k = sp->rice[pj - first_j], eb = sp->escape_bits[pj - first_j];
@@ -3195,7 +2734,6 @@ __device__ __forceinline__ void pack_subframe(const Params &p, const PackParams 
     }
 }
 
-template <int MODE, int PREV>
 __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     uint32_t frame, ch;
@@ -3217,7 +2755,7 @@ __global__ void __launch_bounds__(WG) k_pack(Params p, PackParams q) {
 
     uint32_t *sb = reinterpret_cast<uint32_t *>(lds);  // the subframe's bit string
     for (uint32_t i = tid; i < nwords; i += WG) sb[i] = 0;
-    pack_subframe<MODE, PREV>(p, q, frame, ch, n, sb, prefix_bits, ch == 0, lds + pack_sb_words(FN), hc, fn);
+    pack_subframe(p, q, frame, ch, n, sb, prefix_bits, ch == 0, hc, fn);
     __syncthreads();
     // copy out: absolute bit position of sb[0] in the output stream
     const uint64_t abs_bit = q.frame_off[frame] * 8ull + (ch == 0 ? 0u : start_bit);
@@ -3305,100 +2843,6 @@ __constant__ __attribute__((aligned(16))) CrcTables kCrcT = CrcTables();
 // CRC-16 + one guard word for the funnel shifts); multiple of 4 words
 __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps, uint32_t n = FN) {
     return (((16u + 2u) * 8u + channels * (n * (bps + 1u) + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
-}
-
-// ---------------------------------------------------------------------------------
-// K9+K10 fused for 4096-sample frames: ONE workgroup assembles a whole frame in LDS -- header,
-// every subframe at its bit offset (the same pack_subframe as k_pack), byte-alignment padding --
-// computes the CRC-16 from LDS (256 slices of 17 words: conflict-free strides, GF(2)-linear
-// combination as in k_crc), appends it and writes the finished bytes to HBM once, with plain
-// stores (interior dwords) and byte stores (the two ends): no zero-fill of the output, no
-// atomics, and the frame is never read back from HBM.
-// ---------------------------------------------------------------------------------
-template <int PREV>
-__global__ void __launch_bounds__(WG) k_frame(Params p, PackParams q, uint32_t fb_words) {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ uint16_t T[4][256];  // slicing-by-4 tables
-    __shared__ uint32_t part[4];
-    const uint32_t frame = p.f0 + blockIdx.x, tid = threadIdx.x;
-    uint32_t *fb = reinterpret_cast<uint32_t *>(lds);
-    int32_t *xs = lds + fb_words;
-    const uint64_t fn = q.first_frame_number + frame;
-    const HeaderCodes hc = header_codes(FN, q.sample_rate, fn);
-    const uint64_t begin = q.frame_off[frame];
-    const uint32_t flen = (uint32_t)(q.frame_off[frame + 1] - begin);  // bytes, CRC-16 included
-    const uint32_t nwords = (flen + 3) / 4 + 1;
-    for (uint32_t i = tid; i < nwords; i += WG) fb[i] = 0;
-    {
-        uint32_t c = tid << 8;
-        for (int k = 0; k < 4; k++) {  // T[k][b] = CRC state after byte b followed by k zero bytes
-            for (int b = 0; b < 8; b++) c = (c & 0x8000) ? ((c << 1) ^ 0x8005) & 0xFFFF : (c << 1) & 0xFFFF;
-            T[k][tid] = (uint16_t)c;
-        }
-    }
-    uint32_t start_bit = header_bytes(hc) * 8;
-    for (uint32_t ch = 0; ch < p.channels; ch++) {
-        pack_subframe<2, PREV>(p, q, frame, ch, FN, fb, start_bit, ch == 0, xs, hc, fn);
-        start_bit += p.out_plan[(size_t)frame * p.channels + ch].bits;
-        __syncthreads();
-    }
-    // ---- CRC-16 of bytes [0, len) (crc.rs:142-188); byte i = fb[i / 4] >> (24 - 8 (i % 4))
-    const uint32_t len = flen - 2;
-    constexpr uint32_t CH = WG * 68;                 // bytes per pass
-    const uint32_t my_weight = kCrcW17.w[WG - 1 - tid];
-    const uint32_t xchunk = kCrcW17.w[WG];
-    uint32_t running = 0;
-    for (uint32_t pos = 0; pos < len;) {
-        // the first pass takes the odd-sized head, right-aligned in the 256 x 68-byte window
-        // (left-padded with zero bytes, which leave a zero CRC state unchanged)
-        const uint32_t clen = (pos == 0 && (len % CH)) ? len % CH : CH;
-        const int32_t f0 = (int32_t)pos - (int32_t)(CH - clen) + (int32_t)(68 * tid);  // first frame byte of my slice
-        const int32_t w0 = f0 >> 2;                  // floor: f0 may be negative
-        const uint32_t sh = ((uint32_t)f0 & 3u) * 8u;
-        uint32_t crc = 0;
-        uint32_t cur = w0 >= 0 ? fb[w0] : 0u;
-#pragma unroll
-        for (int k = 0; k < 17; k++) {
-            const int32_t wn = w0 + k + 1;
-            const uint32_t nxt = wn >= 0 ? fb[wn] : 0u;
-            const uint32_t m = sh ? (cur << sh) | (nxt >> (32 - sh)) : cur;
-            crc = T[3][((crc >> 8) ^ (m >> 24)) & 0xFF] ^ T[2][(crc ^ (m >> 16)) & 0xFF] ^
-                  T[1][(m >> 8) & 0xFF] ^ T[0][m & 0xFF];
-            cur = nxt;
-        }
-        uint32_t c = gf_mulmod(crc, my_weight);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c ^= __shfl_xor(c, off, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) part[tid >> 6] = c;
-        __syncthreads();
-        running = gf_mulmod(running, xchunk) ^ part[0] ^ part[1] ^ part[2] ^ part[3];
-        pos += clen;
-    }
-    if (tid == 0) {  // the two CRC bytes follow byte len - 1 (still zero there)
-        atomicOr(&fb[len >> 2], ((running >> 8) & 0xFF) << (24 - 8 * (len & 3)));
-        atomicOr(&fb[(len + 1) >> 2], (running & 0xFF) << (24 - 8 * ((len + 1) & 3)));
-    }
-    __syncthreads();
-    // ---- copy out: output dword j covers frame bytes [4 j - r, 4 j - r + 4)
-    uint8_t *ob = reinterpret_cast<uint8_t *>(q.out_words);
-    const uint32_t r = (uint32_t)(begin & 3);
-    uint32_t *og = reinterpret_cast<uint32_t *>(ob + (begin - r));
-    const uint32_t nout = (r + flen + 3) / 4;
-    for (uint32_t j = tid; j < nout; j += WG) {
-        const uint32_t hi = (r && j == 0) ? 0u : fb[j - (r ? 1u : 0u)];
-        const uint32_t m = r ? (hi << (8 * (4 - r))) | (fb[j] >> (8 * r)) : hi;  // MSB-first window
-        const int32_t fbyte = (int32_t)(4 * j) - (int32_t)r;                     // frame byte of the low address
-        if (fbyte >= 0 && fbyte + 4 <= (int32_t)flen) {
-            og[j] = __builtin_bswap32(m);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int32_t fbk = fbyte + e;
-                if (fbk >= 0 && fbk < (int32_t)flen) ob[begin + fbk] = (uint8_t)(m >> (24 - 8 * e));
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -4454,7 +3898,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_pack<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(pack_lds_bytes((uint32_t)B))));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
@@ -4590,8 +4034,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     // parameters are known): block lengths 64 x {16, 18, 32, 36, 64}, LPC order <= 16
     const bool w64 = narrow && wave_block_size(B) && (p.max_lpc_order <= 16 || B == FN) && p.max_po <= 6 &&
                      !getenv("FLACGPU_NO_W64");
-    const bool fast16 = narrow && B == FN;  // 16-samples-per-lane register kernels (any order)
-    const uint32_t n_fast = (w64 || fast16) ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
+    const uint32_t n_fast = w64 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
     Params pf = p, pg = p;
     pf.f0 = 0;
     pf.fcount = n_fast;
@@ -4608,7 +4051,6 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         HIP_TRY(hipStreamWaitEvent(sf, c->ev_fork, 0));
     }
     begin(2);
-    if (pf.fcount && !w64) hipLaunchKernelGGL(k_fixed16, dim3(pf.fcount * c->ncand), dim3(WG), 0, sf, pf);
     if (pg.fcount) hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, sf, pg);
     if (fork) HIP_TRY(hipEventRecord(c->ev_join, sf));
     if (lpc) {
@@ -4621,12 +4063,6 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         launch_lpc(p, (ncb + 63) / 64, st);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         begin(5);
-        if (pf.fcount && !w64) {
-            if (p.max_lpc_order <= 16)
-                hipLaunchKernelGGL(k_fir16<1>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
-            else
-                hipLaunchKernelGGL(k_fir16<2>, dim3(pf.fcount * c->ncand), dim3(WG), 0, st, pf);
-        }
         if (pg.fcount) hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
     if (w64 && pf.fcount) {
@@ -4722,54 +4158,36 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
     if (c->timing) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
-    // frames of exactly 4096 samples are assembled whole in LDS by k_frame (residuals recomputed
+    // frames of a wave block length are assembled whole in LDS by k_frame64 (residuals recomputed
     // from the PCM, CRC-16 from LDS, one write of the finished bytes); any other frame goes
     // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
     // atomic OR at shared words) -> k_crc
     const uint32_t B = p.block_size;
     const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
-    const bool fast16 = narrow && B == FN;  // k_frame / k_pack<2,*>: 4096 only, any order
     const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
-    const size_t lds_frame = ((size_t)fbw + WG * 20) * sizeof(int32_t);
-    // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}, order <= 16, <= 4 channels
+    // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}; orders 17..32 and 5..8 channels
+    // for 4096-sample blocks only (and not both)
     const bool f64w = narrow && wave_block_size(B) &&
                       (p.max_lpc_order <= 16 || (B == FN && p.channels <= 4)) &&
                       (p.channels <= 4 || B == FN) && p.max_po <= 6 &&
                       (size_t)fbw * sizeof(int32_t) <= 150 * 1024 &&
                       !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64");
-    const uint32_t n_fast = (fast16 || f64w) ? (p.last_len == B ? p.n_frames : p.n_frames - 1) : 0;
-    const bool fused = n_fast && (f64w || (lds_frame <= 64 * 1024 && !getenv("FLACGPU_NO_FUSED_PACK")));
+    const uint32_t n_fast = f64w ? (p.last_len == B ? p.n_frames : p.n_frames - 1) : 0;
+    const bool fused = n_fast != 0;
     Params pf = p, pg = p;
     pf.f0 = 0;
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = p.n_frames - n_fast;
-    const bool need_zero = !fused || pg.fcount;
-    if (need_zero) hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
+    if (pg.fcount) hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
     if (c->timing) (void)hipEventRecord(ev[1], st);
-    {
-        const size_t lds = pack_lds_bytes(p.block_size);
-        if (pf.fcount && f64w) {  // wave per subframe
-            launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
-        } else if (pf.fcount && fused) {
-            if (p.max_lpc_order <= 16)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<1>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame<2>), dim3(pf.fcount), dim3(WG), lds_frame, st, pf, q, fbw);
-        } else if (pf.fcount) {
-            const size_t lds2 = lds + WG * 20 * sizeof(int32_t);
-            if (p.max_lpc_order <= 16)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<2, 1>), dim3(pf.fcount * p.channels), dim3(WG), lds2, st, pf, q);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<2, 2>), dim3(pf.fcount * p.channels), dim3(WG), lds2, st, pf, q);
+    if (pf.fcount) launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
+    if (pg.fcount) {
+        if (!c->resid_valid) {  // residual rows of these frames
+            hipLaunchKernelGGL(k_emit, dim3(pg.fcount * p.channels), dim3(WG),
+                               (size_t)p.block_size * sizeof(int32_t), st, pg);
         }
-        if (pg.fcount) {
-            if (!c->resid_valid) {  // residual rows of these frames
-                hipLaunchKernelGGL(k_emit, dim3(pg.fcount * p.channels), dim3(WG),
-                                   (size_t)p.block_size * sizeof(int32_t), st, pg);
-            }
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pack<0, 1>), dim3(pg.fcount * p.channels), dim3(WG), lds, st, pg, q);
-        }
+        hipLaunchKernelGGL(k_pack, dim3(pg.fcount * p.channels), dim3(WG), pack_lds_bytes(p.block_size), st, pg, q);
     }
     if (c->timing) (void)hipEventRecord(ev[2], st);
     {   // CRC-16 of the frames that did not take the fused kernel

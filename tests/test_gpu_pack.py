@@ -166,3 +166,14 @@ def test_wave_kernels_edge_inputs(block):
     click[block + 10] = 30000
     click[block * 3 + 1] = -32768
     run_case(click, 2, 16, block_size=block)
+
+
+def test_generic_kernels_at_wave_block_lengths(monkeypatch):
+    """FLACGPU_NO_W64 / FLACGPU_NO_FRAME64 route 4096- and 1152-sample frames through the generic
+    LDS kernels (k_fixed, k_fir, k_autocorr*, k_emit, k_pack, k_crc): same bytes."""
+    monkeypatch.setenv("FLACGPU_NO_W64", "1")
+    monkeypatch.setenv("FLACGPU_NO_FRAME64", "1")
+    run_case(synth_fast(600, 2, 24, 4096 * 4 + 100), 2, 24)
+    run_case(synth_fast(601, 2, 16, 1152 * 5), 2, 16, block_size=1152, max_po=3, max_lpc=0, mid_side=False,
+             exhaustive=False)
+    run_case(synth_fast(602, 2, 24, 4096 * 3), 2, 24, max_lpc=32)
