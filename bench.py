@@ -219,6 +219,15 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                     "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
+        if dom == "k_cand64":
+            # SURVEY 8(d) prices the stages this kernel fuses separately (K1 FIXED 8 B, K4 FIR 8 B,
+            # K5 Rice search 4 B per candidate sample); the fusion removes all but one 4-byte read.
+            fused = 20.0 * cand_samples
+            roofline["unfused_accounting"] = {
+                "bytes": fused, "equivalent_GB/s": round(fused / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
+                "fir_stage_alone_GB/s": round(8.0 * cand_samples / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
+                "note": "K1 8 B + K4 8 B + K5 4 B per candidate sample (SURVEY 8(d)); `achieved` above "
+                        "counts only the bytes the fused kernel still has to move"}
         # The integer kernels are bound by VALU instruction issue, not by HBM: one wave64 VALU
         # instruction holds a SIMD for 4 cycles, so the chip issues at most 1024 SIMDs x clk / 4
         # wave-instructions per second.  Instruction counts per launch come from the SQ_INSTS_VALU
