@@ -290,7 +290,8 @@ def main():
             "config": {"workload": "48 kHz/24-bit stereo, blocksize 4096, level 8 (Options::best: "
                                    "LPC order 12, partition order 6, mid-side, exhaustive), "
                                    f"{F} frames per GPU per step, PCM resident in HBM, frame bytes "
-                                   "produced in HBM",
+                                   f"produced in HBM; consecutive batches rotate through {len(ans)} "
+                                   "encoder context(s) on separate HIP streams",
                        "frames_per_gpu": F, "parallelism": f"frame ranges x{world}",
                        "contexts": len(ans)},
             "roofline": roofline,
