@@ -1,0 +1,91 @@
+"""Seeded random sweep over options x stream parameters x signal kinds: device frames (analysis +
+assembly through the C ABI) must equal the oracle's, frame by frame.  The sweep mixes the block
+lengths of the wave kernels with arbitrary ones, 1..8 channels, 8..32 bits, every LPC order,
+partition orders 0..6, all channel-correlation modes and short last frames."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import synth_fast
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("FLAC_RANDOM_CASES", "80"))
+
+
+def make_signal(rng, kind, channels, bps, n):
+    full = 1 << (bps - 1)
+    if kind == "synth":
+        return synth_fast(int(rng.integers(1 << 30)), channels, bps, n)
+    if kind == "noise":
+        return rng.integers(-full, full, size=n * channels, dtype=np.int64).astype(np.int32)
+    if kind == "silence":
+        return np.zeros(n * channels, dtype=np.int32)
+    if kind == "sparse":
+        x = np.zeros(n * channels, dtype=np.int32)
+        idx = rng.integers(0, x.size, size=max(1, x.size // 500))
+        x[idx] = rng.integers(-full, full, size=idx.size, dtype=np.int64).astype(np.int32)
+        return x
+    if kind == "quiet":
+        return rng.integers(-3, 4, size=n * channels, dtype=np.int64).astype(np.int32)
+    if kind == "shifted":  # wasted bits
+        sh = int(rng.integers(1, min(8, bps - 2)))
+        base = synth_fast(int(rng.integers(1 << 30)), channels, bps - sh, n).astype(np.int64)
+        return (base << sh).astype(np.int32)
+    if kind == "sine":
+        t = np.arange(n, dtype=np.float64)
+        cols = [np.round((full - 1) * 0.9 * np.sin(2 * np.pi * (0.001 + 0.01 * c) * t + c)) for c in range(channels)]
+        return np.stack(cols, axis=1).reshape(-1).astype(np.int32)
+    raise ValueError(kind)
+
+
+def one_case(seed):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    block = int(rng.choice([1024, 1152, 2048, 2304, 4096, 4096, 4096, 192, 576, 1000, 4608, 16, 333, 8192]))
+    channels = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 8]))
+    bps = int(rng.choice([8, 12, 16, 16, 20, 24, 24, 32]))
+    max_lpc = int(rng.choice([0, 1, 4, 8, 12, 12, 16, 17, 32]))
+    max_lpc = min(max_lpc, 32)
+    tz = (block & -block).bit_length() - 1
+    max_po = int(rng.integers(0, 7))
+    if min(tz, max_po) > 6:
+        max_po = 6
+    mid_side = bool(rng.integers(2))
+    exhaustive = bool(rng.integers(2))
+    window = [(0, 0.0), (1, 0.0), (2, 0.5), (2, 0.25)][int(rng.integers(4))]
+    n_frames = int(rng.integers(1, 6))
+    last = block if rng.integers(3) else int(rng.integers(1, block + 1))
+    if block <= max_lpc:   # the reference needs n > order for LPC; keep the case meaningful
+        max_lpc = 0
+    kind = str(rng.choice(["synth", "synth", "synth", "noise", "silence", "sparse", "quiet", "shifted", "sine"]))
+    if kind == "shifted" and bps < 12:
+        kind = "synth"
+    n = (n_frames - 1) * block + last
+    pcm = make_signal(rng, kind, channels, bps, n)
+    rate = int(rng.choice([8000, 44100, 48000, 96000, 192000, 12345]))
+    first = int(rng.choice([0, 127, 128, 70000, (1 << 31) - 8]))
+    desc = (f"seed {seed}: block {block} ch {channels} bps {bps} lpc {max_lpc} po {max_po} ms {mid_side} "
+            f"ex {exhaustive} win {window} frames {n_frames} last {last} {kind} rate {rate} first {first}")
+    an = GpuAnalyzer(block, max_po, max_lpc, mid_side, exhaustive, window[0], window[1], bps, channels,
+                     max_frames=n_frames)
+    try:
+        data, off = an.encode_frames(pcm, n_frames, last, first, rate)
+    finally:
+        an.close()
+    oopts = orc_options_for(block, max_po, max_lpc, mid_side, exhaustive, window[0], window[1])
+    for f, planar in enumerate(planar_frames(pcm, channels, block)):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)
+        assert rc == 0, desc
+        assert data[off[f]:off[f + 1]] == fb, f"frame {f} differs: {desc}"
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_random_configs(chunk):
+    per = (N_CASES + 7) // 8
+    for i in range(per):
+        one_case(1000 * chunk + i)
