@@ -56,6 +56,10 @@ namespace {
 
 }  // namespace
 
+struct flacgpu_ctx;
+static int ctx_sync(flacgpu_ctx *c);
+static hipStream_t ctx_stream(flacgpu_ctx *c);
+
 struct flacgpu_ctx {
     flacgpu_options opts;
     uint32_t bps, channels, max_frames, ldb, ncand, stereo4;
@@ -84,6 +88,7 @@ struct flacgpu_ctx {
     Params last_params;
     uint32_t window_last_len = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;  // stream the last analysis / assembly was submitted to
     // last call
     uint32_t last_frames = 0, last_len = 0;
     bool timing = false;
@@ -92,6 +97,18 @@ struct flacgpu_ctx {
     bool ev_used[FLACGPU_N_KERNELS];
     float last_ms[FLACGPU_N_KERNELS];
 };
+
+// Waits for the work this context submitted last (never for other contexts: no device-wide sync).
+static hipStream_t ctx_stream(flacgpu_ctx *c) { return c->last_stream ? c->last_stream : c->own_stream; }
+static int ctx_sync(flacgpu_ctx *c) {
+    HIP_TRY(hipStreamSynchronize(ctx_stream(c)));
+    return FLACGPU_OK;
+}
+// blocking copy ordered after this context's work only
+static int copy_sync(flacgpu_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind, ctx_stream(c)));
+    return ctx_sync(c);
+}
 
 namespace {
 
@@ -407,7 +424,8 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
     ALLOC(c->d_frame_off, F + 1);
 #undef ALLOC
-    HIP_TRY(hipStreamCreate(&c->own_stream));
+    // non-blocking: contexts must not synchronise with each other through the legacy null stream
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -605,6 +623,7 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     c->last_frames = n_frames;
     c->last_len = last_len;
     c->last_params = p;
+    c->last_stream = st;
     c->packed_valid = false;
     if (c->timing) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -620,12 +639,12 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
 
 static int ensure_residual_rows(flacgpu_ctx *c) {
     if (c->resid_valid) return FLACGPU_OK;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = ctx_sync(c)) return rc;
     const Params &p = c->last_params;
     hipLaunchKernelGGL(k_emit, dim3(p.n_frames * p.channels), dim3(WG),
-                       (size_t)p.block_size * sizeof(int32_t), c->own_stream, p);
+                       (size_t)p.block_size * sizeof(int32_t), ctx_stream(c), p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    if (int rc = ctx_sync(c)) return rc;
     c->resid_valid = true;
     return FLACGPU_OK;
 }
@@ -635,7 +654,7 @@ int flacgpu_fetch(flacgpu_ctx *c, flacgpu_frame_plan *plans, flacgpu_subframe_pl
     if (!c || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
     const size_t F = c->last_frames;
     hipStream_t st = c->own_stream;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = ctx_sync(c)) return rc;
     if (residuals)
         if (int rc = ensure_residual_rows(c)) return rc;
     if (plans) HIP_TRY(hipMemcpyAsync(plans, c->d_fplan, sizeof(*plans) * F, hipMemcpyDeviceToHost, st));
@@ -725,6 +744,7 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     if (c->timing) (void)hipEventRecord(ev[3], st);
     HIP_TRY(hipGetLastError());
     c->packed_valid = true;
+    c->last_stream = st;
     if (c->timing) {
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < 3; i++) {
@@ -826,6 +846,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     c->last_frames = n_frames;
     c->last_len = last_len;
     c->last_params = p;
+    c->last_stream = st0;
     c->packed_valid = true;
     return FLACGPU_OK;
 }
@@ -837,21 +858,21 @@ int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *off
         return FLACGPU_ERR_INVALID_ARG;
     }
     const size_t F = c->last_frames;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = ctx_sync(c)) return rc;
     std::vector<uint64_t> off;
     uint64_t *offp = offsets;
     if (!offp) {
         off.resize(F + 1);
         offp = off.data();
     }
-    HIP_TRY(hipMemcpy(offp, c->d_frame_off, sizeof(uint64_t) * (F + 1), hipMemcpyDeviceToHost));
+    if (int rc = copy_sync(c, offp, c->d_frame_off, sizeof(uint64_t) * (F + 1), hipMemcpyDeviceToHost)) return rc;
     const uint64_t bytes = offp[F];
     if (total) *total = bytes;
     if (!out || cap < bytes) {
         g_last_error = "output buffer too small";
         return FLACGPU_ERR_BUFFER_TOO_SMALL;
     }
-    HIP_TRY(hipMemcpy(out, c->d_packed, bytes, hipMemcpyDeviceToHost));
+    if (int rc = copy_sync(c, out, c->d_packed, bytes, hipMemcpyDeviceToHost)) return rc;
     return FLACGPU_OK;
 }
 
@@ -884,9 +905,9 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
     const size_t nc = (size_t)p.n_frames * p.ncand;
     std::vector<LpcParams> exact(nc), mfma(nc);
     std::vector<double> ac_exact(nc * AC_LD), ac_mfma(nc * AC_LD);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(exact.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ac_exact.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost));
+    if (int rc = ctx_sync(c)) return rc;
+    if (int rc = copy_sync(c, exact.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost)) return rc;
+    if (int rc = copy_sync(c, ac_exact.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost)) return rc;
     // warm-up + timed launch of the MFMA kernel, writing into the regular ac buffer
     for (int it = 0; it < 2; it++) {
         if (it == 1) (void)hipEventRecord(c->ev[0], st);
@@ -898,11 +919,11 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-    HIP_TRY(hipMemcpy(mfma.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ac_mfma.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost));
+    if (int rc = copy_sync(c, mfma.data(), c->d_lpc, sizeof(LpcParams) * nc, hipMemcpyDeviceToHost)) return rc;
+    if (int rc = copy_sync(c, ac_mfma.data(), c->d_ac, sizeof(double) * nc * AC_LD, hipMemcpyDeviceToHost)) return rc;
     // restore the exact results so that the context stays consistent
-    HIP_TRY(hipMemcpy(c->d_lpc, exact.data(), sizeof(LpcParams) * nc, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_ac, ac_exact.data(), sizeof(double) * nc * AC_LD, hipMemcpyHostToDevice));
+    if (int rc = copy_sync(c, c->d_lpc, exact.data(), sizeof(LpcParams) * nc, hipMemcpyHostToDevice)) return rc;
+    if (int rc = copy_sync(c, c->d_ac, ac_exact.data(), sizeof(double) * nc * AC_LD, hipMemcpyHostToDevice)) return rc;
     uint32_t cmp = 0, diff = 0;
     double worst = 0.0;
     for (size_t i = 0; i < nc; i++) {
@@ -944,7 +965,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     q.out_words = c->d_packed;
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = ctx_sync(c)) return rc;
     HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * 4, st));
     // compare against the planar PCM the analysis consumed, when it is the context's own copy
     const int32_t *expect = (p.planar == c->d_planar && p.ldb == c->ldb) ? c->d_planar : nullptr;
@@ -958,7 +979,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     uint32_t counts[4];
-    HIP_TRY(hipMemcpy(counts, c->d_verify, sizeof counts, hipMemcpyDeviceToHost));
+    if (int rc = copy_sync(c, counts, c->d_verify, sizeof counts, hipMemcpyDeviceToHost)) return rc;
     result->frames = p.n_frames;
     result->bad_structure = counts[0];
     result->bad_crc16 = counts[1];
@@ -977,8 +998,8 @@ int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
     if (!c || !c->d_decoded || !interleaved || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
     const size_t F = c->last_frames, C = c->channels, B = c->opts.block_size, ldb = c->ldb;
     std::vector<int32_t> planar(F * C * ldb);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(planar.data(), c->d_decoded, sizeof(int32_t) * planar.size(), hipMemcpyDeviceToHost));
+    if (int rc = ctx_sync(c)) return rc;
+    if (int rc = copy_sync(c, planar.data(), c->d_decoded, sizeof(int32_t) * planar.size(), hipMemcpyDeviceToHost)) return rc;
     size_t o = 0;
     for (size_t f = 0; f < F; f++) {
         const size_t n = (f + 1 == F) ? c->last_len : B;
@@ -991,8 +1012,8 @@ int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
 int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     if (!c || !out) return FLACGPU_ERR_INVALID_ARG;
     uint32_t s[4];
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(s, c->d_stats, sizeof s, hipMemcpyDeviceToHost));
+    if (int rc = ctx_sync(c)) return rc;
+    if (int rc = copy_sync(c, s, c->d_stats, sizeof s, hipMemcpyDeviceToHost)) return rc;
     out->frames = c->last_frames;
     out->lpc_failed = s[0];
     out->order_ties = s[1];

@@ -13,6 +13,7 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <mutex>
 #include <vector>
 
 #include "bitsink.h"
@@ -244,6 +245,50 @@ int pack_batch(uint32_t sample_rate, uint32_t bps, uint32_t channels, uint64_t f
 // =====================================================================================
 // Encoder<W>, encode.rs:1853-2110
 // =====================================================================================
+// Idle analysis contexts, keyed by everything flacgpu_create depends on.  Creating a context costs
+// a dozen hipMalloc calls and destroying it as many hipFree calls, which synchronise the whole
+// device: with many short streams (a music library) they dominate.  Writers return their context
+// here; at most kPoolCap idle contexts are kept (the rest are destroyed), the process exit reclaims.
+struct CtxKey {
+    flacgpu_options g;
+    uint32_t bps, channels, batch;
+    int device;
+    bool operator==(const CtxKey &o) const {
+        return std::memcmp(&g, &o.g, sizeof g) == 0 && bps == o.bps && channels == o.channels &&
+               batch == o.batch && device == o.device;
+    }
+};
+struct CtxPool {
+    static constexpr size_t kPoolCap = 64;
+    std::mutex mu;
+    std::vector<std::pair<CtxKey, flacgpu_ctx *>> idle;
+    flacgpu_ctx *take(const CtxKey &k) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < idle.size(); i++) {
+            if (idle[i].first == k) {
+                flacgpu_ctx *c = idle[i].second;
+                idle.erase(idle.begin() + static_cast<ptrdiff_t>(i));
+                return c;
+            }
+        }
+        return nullptr;
+    }
+    void give(const CtxKey &k, flacgpu_ctx *c) {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (idle.size() < kPoolCap) {
+                idle.emplace_back(k, c);
+                return;
+            }
+        }
+        flacgpu_destroy(c);
+    }
+};
+CtxPool &ctx_pool() {
+    static CtxPool *p = new CtxPool();  // intentionally leaked: no HIP calls during static destruction
+    return *p;
+}
+
 struct flacenc_writer {
     enum Kind { SAMPLE, BYTE, CHANNEL } kind = SAMPLE;
     flacenc_options o{};
@@ -272,8 +317,9 @@ struct flacenc_writer {
     std::vector<uint8_t> outbuf;  // frames fetched from the device
     flacenc_stats stats{};
 
+    CtxKey gpu_key{};
     ~flacenc_writer() {
-        if (gpu) flacgpu_destroy(gpu);
+        if (gpu) ctx_pool().give(gpu_key, gpu);
     }
 
     // Encoder::new, encode.rs:1882-1980
@@ -335,36 +381,52 @@ struct flacenc_writer {
         unsigned hw = std::thread::hardware_concurrency();
         pack_threads = o.pack_threads ? o.pack_threads : std::max(1u, std::min(hw, 16u));
         flacgpu_options g = gpu_options(o, o.block_size);
-        int rc = flacgpu_create(&g, bps, channels, o.device, batch_frames, &gpu);
-        if (rc) return map_gpu_error(rc);
+        std::memset(&gpu_key, 0, sizeof gpu_key);
+        gpu_key.g = g;
+        gpu_key.bps = bps;
+        gpu_key.channels = channels;
+        gpu_key.batch = batch_frames;
+        gpu_key.device = o.device;
+        gpu = ctx_pool().take(gpu_key);
+        if (!gpu) {
+            int rc = flacgpu_create(&g, bps, channels, o.device, batch_frames, &gpu);
+            if (rc) return map_gpu_error(rc);
+        }
         return 0;
     }
 
     // update_md5, encode.rs:1292-1318: little-endian, ceil(bps/8) bytes per sample
+    // MD5 over the samples as little-endian bytes_per_sample-byte integers (encode.rs:571), converted
+    // through a small fixed buffer (a whole-call buffer costs as many page faults as the PCM itself)
     void md5_samples(const int32_t *s, size_t count) {
         double t0 = now_ms();
-        md5_bytes.resize(count * bytes_per_sample);
+        constexpr size_t CHUNK = 1 << 16;  // samples
+        if (md5_bytes.size() < CHUNK * 4) md5_bytes.resize(CHUNK * 4);
         uint8_t *d = md5_bytes.data();
-        switch (bytes_per_sample) {
-        case 1: for (size_t i = 0; i < count; i++) d[i] = static_cast<uint8_t>(s[i]); break;
-        case 2:
-            for (size_t i = 0; i < count; i++) {
-                uint32_t v = static_cast<uint32_t>(s[i]);
-                d[2 * i] = static_cast<uint8_t>(v);
-                d[2 * i + 1] = static_cast<uint8_t>(v >> 8);
+        for (size_t base = 0; base < count; base += CHUNK) {
+            const size_t m = std::min(CHUNK, count - base);
+            const int32_t *q = s + base;
+            switch (bytes_per_sample) {
+            case 1: for (size_t i = 0; i < m; i++) d[i] = static_cast<uint8_t>(q[i]); break;
+            case 2:
+                for (size_t i = 0; i < m; i++) {
+                    uint32_t v = static_cast<uint32_t>(q[i]);
+                    d[2 * i] = static_cast<uint8_t>(v);
+                    d[2 * i + 1] = static_cast<uint8_t>(v >> 8);
+                }
+                break;
+            case 3:
+                for (size_t i = 0; i < m; i++) {
+                    uint32_t v = static_cast<uint32_t>(q[i]);
+                    d[3 * i] = static_cast<uint8_t>(v);
+                    d[3 * i + 1] = static_cast<uint8_t>(v >> 8);
+                    d[3 * i + 2] = static_cast<uint8_t>(v >> 16);
+                }
+                break;
+            default: std::memcpy(d, q, m * 4); break;
             }
-            break;
-        case 3:
-            for (size_t i = 0; i < count; i++) {
-                uint32_t v = static_cast<uint32_t>(s[i]);
-                d[3 * i] = static_cast<uint8_t>(v);
-                d[3 * i + 1] = static_cast<uint8_t>(v >> 8);
-                d[3 * i + 2] = static_cast<uint8_t>(v >> 16);
-            }
-            break;
-        default: std::memcpy(d, s, count * 4); break;
+            md5.update(d, m * bytes_per_sample);
         }
-        md5.update(d, md5_bytes.size());
         stats.md5_ms += now_ms() - t0;
     }
 
@@ -410,12 +472,14 @@ struct flacenc_writer {
             } else {
                 // frames assembled on the device: only the finished bytes cross PCIe
                 std::vector<uint64_t> off(usable + 1);
-                const size_t need = (static_cast<size_t>(usable - 1) * B + ll) * C * 4 + usable * 128 + 1024;
-                if (outbuf.size() < need) outbuf.resize(need);  // grown once, reused by every batch
                 uint64_t total = 0;
+                // first the sizes, then a buffer of exactly that size (grown, reused by every batch)
                 int rc = flacgpu_encode_frames(gpu, interleaved, FLACGPU_LAYOUT_INTERLEAVED, usable, ll,
-                                               frame_number, si.sample_rate, outbuf.data(),
-                                               outbuf.size(), off.data(), &total);
+                                               frame_number, si.sample_rate, nullptr, 0, off.data(), &total);
+                if (rc == FLACGPU_ERR_BUFFER_TOO_SMALL) {
+                    if (outbuf.size() < total) outbuf.resize(total);
+                    rc = flacgpu_fetch_frames(gpu, outbuf.data(), outbuf.size(), off.data(), &total);
+                }
                 stats.gpu_ms += now_ms() - t0;
                 if (rc) return map_gpu_error(rc);
                 pb.offsets.assign(off.begin(), off.end());
@@ -445,31 +509,61 @@ struct flacenc_writer {
         return deferred;
     }
 
-    // cut whole blocks out of the backlog, batch by batch
-    int drain(bool final_flush) {
+    // Cut whole blocks out of `data` (count samples), batch by batch; returns the samples consumed
+    // through *consumed_out: whole batches, or every whole block at the final flush.
+    int process(const int32_t *data, size_t count, bool final_flush, size_t *consumed_out) {
         const size_t frame_samples = static_cast<size_t>(o.block_size) * si.channels;
         size_t consumed = 0;
         int rc = 0;
-        // blocks this call will cut: whole batches, or everything at the final flush
-        size_t whole_all = backlog.size() / frame_samples;
+        size_t whole_all = count / frame_samples;
         if (!final_flush) whole_all -= whole_all % batch_frames;
         // The stream MD5 is one serial chain over the PCM (encode.rs:571): it runs on its own
         // host thread over the samples of this call while the GPU batches are in flight
         std::future<void> md5_job;
         if (whole_all)
-            md5_job = std::async(std::launch::async, [this, n = whole_all * frame_samples]() {
-                md5_samples(backlog.data(), n);
+            md5_job = std::async(std::launch::async, [this, data, n = whole_all * frame_samples]() {
+                md5_samples(data, n);
             });
         while (rc == 0 && consumed < whole_all * frame_samples) {
             size_t whole = whole_all - consumed / frame_samples;
             uint32_t take = static_cast<uint32_t>(std::min<size_t>(whole, batch_frames));
-            const int32_t *src = backlog.data() + consumed;
-            rc = encode_blocks(src, take, o.block_size);
+            rc = encode_blocks(data + consumed, take, o.block_size);
             consumed += take * frame_samples;
         }
         if (md5_job.valid()) md5_job.get();
+        *consumed_out = consumed;
+        return rc;
+    }
+
+    // cut whole blocks out of the backlog
+    int drain(bool final_flush) {
+        size_t consumed = 0;
+        int rc = process(backlog.data(), backlog.size(), final_flush, &consumed);
         if (consumed) backlog.erase(backlog.begin(), backlog.begin() + static_cast<ptrdiff_t>(consumed));
         return rc;
+    }
+
+    // FlacSampleWriter::write (encode.rs:558-585) without staging the caller's samples: once the
+    // backlog has been topped up to a whole batch and drained, whole batches are encoded straight
+    // from the caller's buffer and only the tail (< one batch) is kept
+    int write_direct(const int32_t *samples, size_t count) {
+        const size_t batch_samples = static_cast<size_t>(batch_frames) * o.block_size * si.channels;
+        if (!backlog.empty()) {
+            const size_t room = backlog.size() < batch_samples ? batch_samples - backlog.size() : 0;
+            const size_t take = std::min(room, count);
+            backlog.insert(backlog.end(), samples, samples + take);
+            samples += take;
+            count -= take;
+            if (int rc = drain(false)) return rc;
+        }
+        if (backlog.empty() && count >= batch_samples) {
+            size_t consumed = 0;
+            if (int rc = process(samples, count, false, &consumed)) return rc;
+            samples += consumed;
+            count -= consumed;
+        }
+        backlog.insert(backlog.end(), samples, samples + count);
+        return drain(false);
     }
 
     // FlacSampleWriter::finalize_inner, encode.rs:588-611, then Encoder::finalize_inner :2024
@@ -665,8 +759,7 @@ int flacenc_channel_writer_new(const flacenc_options *opts, uint32_t rate, uint3
 int flacenc_write_samples(flacenc_writer *w, const int32_t *samples, size_t count) {
     if (!w || (!samples && count)) return FLACENC_ERR_INVALID_ARG;
     if (w->finalized) return FLACENC_ERR_FINALIZED;
-    w->backlog.insert(w->backlog.end(), samples, samples + count);
-    return w->drain(false);
+    return w->write_direct(samples, count);
 }
 
 int flacenc_write_bytes(flacenc_writer *w, const uint8_t *bytes, size_t count) {
