@@ -492,7 +492,6 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.f0 = 0;
     p.fcount = n_frames;
     p.ac_split = (uint32_t)c->lag_split;
-    { const char *e = getenv("FLACGPU_DEBUG"); p.dbg = e ? (uint32_t)atoi(e) : 0; }
     p.planar = c->d_planar;
     p.window_full = c->d_window_full;
     p.window_last = c->d_window_last;
