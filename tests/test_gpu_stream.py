@@ -221,3 +221,47 @@ def test_vorbis_comment_tags():  # Options::tag, encode.rs:1513-1520; block orde
     data = encode_samples(opts, 44100, 16, 2, pcm)
     rc, ref, _ = orc.encode_stream(orc_opts_from(opts), 44100, 16, 2, pcm, tags=["A=b"], vendor="me")
     assert rc == 0 and data == ref and data[42] == 0x84  # last-block flag on the comment
+
+
+def test_concurrent_writers_and_context_pool():
+    """Many writers at once on Python threads (contexts come from the pool and go back to it),
+    different inputs and options per thread, odd write chunkings (the zero-copy path cuts whole
+    batches out of the caller's buffer): every stream byte-identical to the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from flac_codec_amd.encode import Options
+
+    def job(i):
+        ch, bps = [(2, 16), (2, 24), (1, 16), (2, 16)][i % 4]
+        opts = [Options.best, Options.default, Options.fast, Options.best][i % 4]().batch_frames(8)
+        block = 1152 if i % 4 == 2 else 4096
+        n = block * (20 + i) + 13 * i
+        pcm = synth_fast(700 + i, ch, bps, n)
+        chunk = [None, 4096 * 8 * ch, 9973, 4096 * 8 * ch * 3 + 5][i % 4]
+        data = encode_samples(opts, 44100, bps, ch, pcm, chunk=chunk)
+        check_stream(data, pcm, 44100, bps, ch, opts, True)
+        return len(data)
+
+    for _ in range(2):   # the second round runs entirely on pooled contexts
+        with ThreadPoolExecutor(8) as ex:
+            sizes = list(ex.map(job, range(16)))
+        assert all(s > 0 for s in sizes)
+
+
+def test_tuning_and_encode_device_fallbacks():
+    from flac_codec_amd.gpu import GpuAnalyzer, GpuError
+
+    pcm = synth_fast(720, 2, 24, 4096 * 12)
+    an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=12)
+    ref, ref_off = an.encode_frames(pcm, 12, 4096, 5, 48000)
+    with pytest.raises(GpuError):
+        an.set_tuning(99, 1)
+    with pytest.raises(GpuError):
+        an.set_tuning(an.TUNE_LAG_SPLIT, 3)
+    an.set_tuning(an.TUNE_LAG_SPLIT, 2)
+    an.set_two_ranges(True)            # 12 frames < 256: one range
+    got, off = an.encode_frames(pcm, 12, 4096, 5, 48000)
+    assert got == ref and off == ref_off
+    got, off = an.encode_frames(pcm[: 4096 * 2 * 11 + 2 * 100], 12, 100, 5, 48000)   # short last frame: generic tail
+    assert off[:12] == ref_off[:12] and got[: off[11]] == ref[: ref_off[11]]
+    an.close()
