@@ -205,6 +205,7 @@ def main():
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same
         # command, tools/collect_profiles.sh; corrected as MI355X_MICROARCH.md prescribes)
         traffic = None
+        traffic_src = None
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
             if prof and F == FRAMES:
@@ -213,11 +214,14 @@ def main():
                         "k_deinterleave": "k_deinterleave2"}
                 key = fast.get(dom, dom) if fast.get(dom, dom) in t else dom
                 if key in t:
-                    traffic = {"bytes": t[key]["hbm_bytes"], "source": prof[-1], "kernel": key}
+                    traffic = t[key]["hbm_bytes"]
+                    traffic_src = {"source": "profiles/" + prof[-1], "kernel": key,
+                                   "fetch_bytes": t[key].get("fetch_bytes"), "write_bytes": t[key].get("write_bytes")}
         except Exception:
             traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                     "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
         if dom == "k_cand64":
             # SURVEY 8(d) prices the stages this kernel fuses separately (K1 FIXED 8 B, K4 FIR 8 B,
