@@ -14,6 +14,7 @@ from _pcm import synth_fast
 pytestmark = pytest.mark.gpu
 
 N_CASES = int(os.environ.get("FLAC_RANDOM_CASES", "80"))
+SEED0 = int(os.environ.get("FLAC_RANDOM_SEED0", "0"))
 
 
 def make_signal(rng, kind, channels, bps, n):
@@ -88,4 +89,4 @@ def one_case(seed):
 def test_random_configs(chunk):
     per = (N_CASES + 7) // 8
     for i in range(per):
-        one_case(1000 * chunk + i)
+        one_case(SEED0 + 1000 * chunk + i)
