@@ -177,3 +177,25 @@ def test_generic_kernels_at_wave_block_lengths(monkeypatch):
     run_case(synth_fast(601, 2, 16, 1152 * 5), 2, 16, block_size=1152, max_po=3, max_lpc=0, mid_side=False,
              exhaustive=False)
     run_case(synth_fast(602, 2, 24, 4096 * 3), 2, 24, max_lpc=32)
+
+
+def test_more_than_8192_frames_in_one_batch():
+    """k_layout gives each of its 1024 lanes a run of frames; above 8192 frames the runs are longer
+    than its register path (9 frames per lane here).  Spot frames against the oracle, everything
+    through the device round trip (decode + CRC + PCM compare)."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    n_frames, block = 9000, 1024
+    pcm = synth_fast(800, 2, 16, n_frames * block)
+    an = GpuAnalyzer(block, 6, 8, True, True, 2, 0.5, 16, 2, max_frames=n_frames)
+    data, off = an.encode_frames(pcm, n_frames, block, 3, 44100)
+    oopts = orc_options_for(block, 6, 8, True, True)
+    for f in (0, 1, 4499, 4500, 8191, 8192, n_frames - 1):
+        planar = np.ascontiguousarray(pcm[f * block * 2:(f + 1) * block * 2].reshape(block, 2).T)
+        rc, fb, _ = orc.encode_frame(oopts, 44100, 16, planar, frame_number=3 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f
+    an.analyze(pcm, n_frames, block)
+    an.pack_device(3, 44100)
+    res, _ = an.verify_device(44100, 3)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n_frames, 0, 0, 0)
+    an.close()
