@@ -5,6 +5,7 @@ missing or fails to load, importing anything that needs it raises.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflacenc_amd.so")
@@ -89,11 +90,23 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+_load_lock = threading.Lock()
+
+
 def lib():
-    """Load libflacenc_amd.so.  Fails loudly when the HIP extension is not built."""
+    """Load libflacenc_amd.so.  Fails loudly when the HIP extension is not built.  Thread-safe:
+    writers are used from many threads, and a half-bound library (default `int` return types
+    truncate pointers) must never be visible."""
     global _lib
     if _lib is not None:
         return _lib
+    with _load_lock:
+        if _lib is None:
+            _lib = _load()
+    return _lib
+
+
+def _load():
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
@@ -133,7 +146,6 @@ def lib():
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]
     L.flacgpu_kernel_name.restype = C.c_char_p
-    _lib = L
     return L
 
 

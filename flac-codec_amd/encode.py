@@ -7,6 +7,7 @@ All work is done by libflacenc_amd.so (C ABI in include/flacenc_stream.h, gfx950
 behind include/flacenc_gpu.h).  There is no CPU fallback.
 """
 import ctypes as C
+import threading
 import io
 import os
 
@@ -118,12 +119,19 @@ class Stats(C.Structure):
 
 
 _bound = False
+_bind_lock = threading.Lock()
 
 
 def _stream_lib():
+    """The library with the stream-writer entry points bound (once, under a lock: a thread must
+    never call through a function whose restype is still the default int)."""
     global _bound
     L = _lib.lib()
-    if not _bound:
+    if _bound:
+        return L
+    with _bind_lock:
+        if _bound:
+            return L
         vp, ip = C.c_void_p, C.POINTER(C.c_int32)
         po = C.POINTER(_COptions)
         ps = C.POINTER(_CSink)

@@ -265,3 +265,31 @@ def test_tuning_and_encode_device_fallbacks():
     got, off = an.encode_frames(pcm[: 4096 * 2 * 11 + 2 * 100], 12, 100, 5, 48000)   # short last frame: generic tail
     assert off[:12] == ref_off[:12] and got[: off[11]] == ref[: ref_off[11]]
     an.close()
+
+
+def test_first_use_from_many_threads_in_a_fresh_process():
+    """The ctypes binding is set up lazily; doing that from 16 threads at once used to expose a
+    half-bound library (default int return type = truncated pointer -> crash in getvalue)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, hashlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from concurrent.futures import ThreadPoolExecutor
+from _pcm import synth_fast
+pcm = synth_fast(900, 2, 16, 4096 * 40)
+def job(i):
+    from flac_codec_amd.encode import FlacSampleWriter, Options
+    w = FlacSampleWriter(None, Options.best().batch_frames(8), 44100, 16, 2, pcm.size)
+    w.write(pcm); w.finalize(); d = w.getvalue(); w.close()
+    return hashlib.sha256(d).hexdigest()
+with ThreadPoolExecutor(16) as ex:
+    hs = set(ex.map(job, range(64)))
+assert len(hs) == 1, hs
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
