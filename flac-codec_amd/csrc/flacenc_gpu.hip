@@ -25,7 +25,7 @@
 //   K9+10 k_frame64 (pack.inc): a frame assembled in LDS, wave per subframe, CRC-16, one write
 //           stream.rs:242-276, 1390-1413, 1603-1619; encode.rs:3078-3135, 3834-3907, 2408-2409;
 //         generic: k_zero + k_pack + k_crc
-//   N3    k_decode (decode.inc)  decode.rs:1388-1856 read_frame .. predict, one lane per frame
+//   N3    k_decode (decode.inc)  decode.rs:1388-1856 read_frame .. predict, one lane per subframe
 #include <hip/hip_runtime.h>
 
 #include <math.h>
@@ -956,7 +956,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     const size_t F = c->max_frames, C = c->channels;
     if (!c->d_decoded) {
         HIP_TRY(hipMalloc((void **)&c->d_decoded, sizeof(int32_t) * (F * C * c->ldb + 64)));
-        HIP_TRY(hipMalloc((void **)&c->d_verify, sizeof(uint32_t) * 4));
+        HIP_TRY(hipMalloc((void **)&c->d_verify, sizeof(uint32_t) * (4 + F)));  // counters + per-frame codes
     }
     PackParams q;
     q.first_frame_number = first_frame_number;
@@ -965,14 +965,32 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
     if (int rc = ctx_sync(c)) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * 4, st));
+    HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * (4 + (size_t)p.n_frames), st));
     // compare against the planar PCM the analysis consumed, when it is the context's own copy
     const int32_t *expect = (p.planar == c->d_planar && p.ldb == c->ldb) ? c->d_planar : nullptr;
     Params pd = p;
     pd.ldb = c->ldb;
     (void)hipEventRecord(c->ev[0], st);
-    hipLaunchKernelGGL(k_decode, dim3((p.n_frames + 63) / 64), dim3(64), 0, st, pd, q, c->d_decoded,
-                       expect, c->d_verify);
+    {
+        // One lane per subframe.  Every lane reads and writes its own cache lines, so the limit is
+        // the CU's address path (lines per instruction x waves per CU), not the SIMD: measured on
+        // 4096 / 8192 / 32768 stereo frames, 32-lane waves win over 64 (fewer lines per
+        // instruction) and over 16 or 8 (fewer waves per CU): 1.17 / 1.44 / 2.93 ms.
+        const uint32_t units = p.n_frames * p.channels;
+        uint32_t lanes = 32;
+        if (const char *e = getenv("FLACGPU_DECODE_LANES")) {  // experiment knob
+            const uint32_t v = (uint32_t)atoi(e);
+            if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lanes = v;
+        }
+        const dim3 grid((units + lanes - 1) / lanes), block(lanes);
+        const uint32_t mo = c->opts.max_lpc_order;  // FIXED needs 4; the ring is also the store batch
+        if (mo <= 8) hipLaunchKernelGGL(k_decode<8>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
+        else if (mo <= 12) hipLaunchKernelGGL(k_decode<12>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
+        else if (mo <= 16) hipLaunchKernelGGL(k_decode<16>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
+        else hipLaunchKernelGGL(k_decode<32>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
+        hipLaunchKernelGGL(k_decode_finish, dim3(p.n_frames), dim3(WG), 0, st, pd, c->d_decoded, expect,
+                           c->d_verify);
+    }
     hipLaunchKernelGGL(k_crc<true>, dim3(p.n_frames), dim3(WG), 0, st, p, q, c->d_verify);
     (void)hipEventRecord(c->ev[1], st);
     HIP_TRY(hipGetLastError());
