@@ -86,3 +86,33 @@ def test_corruption_is_detected():  # tests/corruption.rs:29-43 shape
     assert (res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (0, 0, 0)
     assert detected >= trials - 2   # the decoder itself also notices almost every flip
     an.close()
+
+
+@pytest.mark.parametrize("ch,bps,block,lpc", [(2, 16, 4096, 12), (8, 24, 576, 12), (1, 16, 1152, 32)])
+def test_heavy_corruption_never_hangs_or_spills_over(ch, bps, block, lpc):
+    """Several flipped / zeroed / saturated bytes per trial: the decoder must come back, flag only
+    frames that were touched, and the CRC-16 must catch at least one of them every time."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    frames = 48
+    pcm = synth_fast(600 + ch + bps, ch, bps, block * frames)
+    an, n_frames, last, data, off = encode(pcm, ch, bps, block=block, lpc=lpc)
+    data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    off = np.asarray(off)
+    dbuf = an.device_buffer(4)
+    rng = np.random.Generator(np.random.PCG64(11 + ch))
+    for _ in range(25):
+        bad = data.copy()
+        for _ in range(int(rng.integers(1, 30))):
+            pos = int(rng.integers(0, len(bad)))
+            kind = int(rng.integers(0, 3))
+            bad[pos] = bad[pos] ^ (1 << int(rng.integers(0, 8))) if kind == 0 else (0 if kind == 1 else 0xFF)
+        touched = {int(np.searchsorted(off, p, side="right") - 1) for p in np.nonzero(bad != data)[0]}
+        assert hip.hipMemcpy(C.c_void_p(dbuf), bad.ctypes.data_as(C.c_void_p), len(bad), 1) == 0
+        res, _ = an.verify_device(48000)
+        assert res.bad_crc16 <= len(touched) and res.bad_structure + res.frames_pcm_differs <= len(touched)
+        assert not touched or res.bad_crc16 >= 1
+    assert hip.hipMemcpy(C.c_void_p(dbuf), data.ctypes.data_as(C.c_void_p), len(data), 1) == 0
+    res, _ = an.verify_device(48000)
+    assert (res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (0, 0, 0)
+    an.close()
