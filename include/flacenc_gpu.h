@@ -210,7 +210,12 @@ int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint
 /* ---- device-side decode + verify of the frames packed last ----------
  * The reference's frame decoder (decode.rs:1388-1436 read_frame, 1494-1633 read_subframes,
  * 1635-1752 read_subframe / predict, 1800-1856 read_residuals) run on the GPU, one lane per
- * frame, over the bytes produced by flacgpu_pack_device, plus a CRC-16 check of every frame.
+ * subframe, over the bytes produced by flacgpu_pack_device, plus a CRC-16 check of every frame.
+ * A lane starts where the encoder's plan says its subframe starts; the plan is proven, not
+ * trusted: subframe 0 must start where the frame header ends, every subframe must end exactly
+ * where the next one starts and the last one at the padding before the CRC-16 (otherwise the
+ * frame counts as bad_structure) -- i.e. the frame parses front to back as a sequential decoder
+ * would parse it.
  * When the analysed PCM is still in the context (host-input or interleaved device input), the
  * decoded samples are compared with it -- the round trip every encoder test of the reference
  * performs (tests/format.rs), without leaving HBM. */

@@ -1,7 +1,8 @@
 """Seeded random sweep over options x stream parameters x signal kinds: device frames (analysis +
 assembly through the C ABI) must equal the oracle's, frame by frame.  The sweep mixes the block
 lengths of the wave kernels with arbitrary ones, 1..8 channels, 8..32 bits, every LPC order,
-partition orders 0..6, all channel-correlation modes and short last frames."""
+partition orders 0..6, all channel-correlation modes and short last frames.  Every case is also
+decoded back on the device and compared with its input."""
 import os
 
 import numpy as np
@@ -76,6 +77,11 @@ def one_case(seed):
                      max_frames=n_frames)
     try:
         data, off = an.encode_frames(pcm, n_frames, last, first, rate)
+        # the device decoder must give the PCM back (k_decode / k_decode_finish / k_crc<VERIFY>)
+        res, _ = an.verify_device(rate, first)
+        assert (res.frames, res.bad_structure, res.bad_crc16) == (n_frames, 0, 0), desc
+        assert res.compared_pcm == 1 and res.frames_pcm_differs == 0 and res.samples_differ == 0, desc
+        assert np.array_equal(an.fetch_decoded(n_frames, last), pcm), desc
     finally:
         an.close()
     oopts = orc_options_for(block, max_po, max_lpc, mid_side, exhaustive, window[0], window[1])
