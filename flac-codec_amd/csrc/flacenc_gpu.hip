@@ -73,7 +73,7 @@ struct flacgpu_ctx {
     FrameInfo *d_finfo = nullptr;
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
-    uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate)
+    uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate); = d_stats + 4
     int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
     uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
@@ -417,8 +417,8 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     ALLOC(c->d_lpc, F * NC);
     ALLOC(c->d_finfo, F);
     ALLOC(c->d_fplan, F);
-    ALLOC(c->d_stats, 4);
-    ALLOC(c->d_orbits, F * NC);
+    ALLOC(c->d_stats, 4 + F * NC);  // counters, then the per-candidate ORs: one memset per batch
+    c->d_orbits = c->d_stats + 4;
     // worst case: every subframe VERBATIM at 32 bits + headers
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
@@ -456,7 +456,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_orbits);
+    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off);
     (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -549,9 +549,8 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
         mark(k);
     };
 
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(uint32_t), st));
     const uint32_t ncb = n_frames * c->ncand;
-    HIP_TRY(hipMemsetAsync(c->d_orbits, 0, sizeof(uint32_t) * ncb, st));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)ncb), st));  // + d_orbits
     // K0 (+ OR of every candidate's samples -> wasted bits)
     const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
     begin(0);
@@ -806,8 +805,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     q.cap_bytes = c->packed_cap;
     const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0);
     if (planar_direct) p.planar = d_pcm;
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(uint32_t), st0));
-    HIP_TRY(hipMemsetAsync(c->d_orbits, 0, sizeof(uint32_t) * n_frames * c->ncand, st0));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st0));  // + d_orbits
     HIP_TRY(hipEventRecord(c->ev_fork, st0));
     HIP_TRY(hipStreamWaitEvent(st1, c->ev_fork, 0));
     const uint32_t h = ((n_frames / 2) + 15u) & ~15u;  // 16 frames = one autocorrelation wave group
