@@ -969,6 +969,12 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     Params pd = p;
     pd.ldb = c->ldb;
     (void)hipEventRecord(c->ev[0], st);
+    // the CRC-16 check only shares the input with the decoder, which leaves half the SIMDs idle:
+    // it runs beside it on the context's second stream
+    HIP_TRY(hipEventRecord(c->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    hipLaunchKernelGGL(k_crc<true>, dim3(p.n_frames), dim3(WG), 0, c->aux_stream, p, q, c->d_verify);
+    HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
     {
         // One lane per subframe.  Every lane reads and writes its own cache lines, so the limit is
         // the CU's address path (lines per instruction x waves per CU), not the SIMD: measured on
@@ -989,7 +995,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
         hipLaunchKernelGGL(k_decode_finish, dim3(p.n_frames), dim3(WG), 0, st, pd, c->d_decoded, expect,
                            c->d_verify);
     }
-    hipLaunchKernelGGL(k_crc<true>, dim3(p.n_frames), dim3(WG), 0, st, p, q, c->d_verify);
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     (void)hipEventRecord(c->ev[1], st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
