@@ -143,6 +143,9 @@ def main():
             rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
             assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
         compressed_bytes = off[F]
+        st = an.stats()
+        analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties, "log2_edge": st.log2_edge,
+                          "candidates": 4 * F}
 
         # ---- per-kernel durations (HIP events on the launch stream), one extra timed pass
         an.set_timing(True)
@@ -316,6 +319,7 @@ def main():
             "compression_ratio": round(compressed_bytes / (F * BLOCK * CHANNELS * 3), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
             "parity_checked_frames": check,
+            "analysis_stats": analysis_stats,
             "shard_counters": counters,
         }
     for a in ans:

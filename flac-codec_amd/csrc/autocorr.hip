@@ -1,0 +1,102 @@
+// autocorr.hip -- K3: window + exact autocorrelation (encode.rs:1785-1801, 3478-3501) and the MFMA experiment.
+// One of the translation units of libflacenc_amd.so (gfx950 only; built with -ffp-contract=off, see
+// Makefile); the kernels are reached through the launchers declared in kernels/types.h.
+#include "kernels/types.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+#include "kernels/common.inc"
+#include "kernels/autocorr.inc"
+
+template <int NL, bool STEREO>
+void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                      const double *win, hipStream_t st) {
+    const uint32_t groups = (nframes * p.ncand + 63) / 64;
+    // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
+    // SIMD to issue at full rate and 8192 frames are only 512 candidate groups (0.23 ms against
+    // 0.31 ms split 2 ways).  When other contexts keep the SIMDs busy anyway, the 2-way split wins:
+    // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
+    // instructions).
+    static const bool private_tiles = getenv("FLACGPU_AC_PRIVATE") != nullptr;  // previous kernel (A/B runs)
+    if (!private_tiles) {  // shared conversion through LDS
+        if (p.ac_split == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
+                               frame0, nframes, n, win);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
+                               frame0, nframes, n, win);
+        return;
+    }
+    if (p.ac_split == 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
+                           frame0, nframes, n, win);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
+                           frame0, nframes, n, win);
+}
+template <bool STEREO>
+void launch_autocorr3_nl(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+                         hipStream_t st) {
+    const uint32_t nl = p.max_lpc_order + 1;
+    if (nl <= 5) launch_autocorr3<5, STEREO>(p, frame0, nframes, n, win, st);
+    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, frame0, nframes, n, win, st);
+    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, frame0, nframes, n, win, st);
+    else launch_autocorr3<17, STEREO>(p, frame0, nframes, n, win, st);
+}
+// frame length a multiple of 32, order <= 16, and either stereo L/R/M/S candidates of <= 24-bit
+// samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
+bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+                   hipStream_t st) {
+    if (n < 32 || n % 32 != 0 || getenv("FLACGPU_NO_AC3")) return false;
+    const bool stereo = p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24;
+    const bool indep = !p.stereo4 && p.ncand == p.channels;
+    if (!stereo && !indep) return false;
+    if (p.max_lpc_order > 16) {  // lags up to 32: two blocks of history, frame a multiple of 64
+        if (n % 64 != 0) return false;
+        const uint32_t groups = (nframes * p.ncand + 63) / 64;
+        if (stereo)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                               nframes, n, win);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
+                               nframes, n, win);
+        return true;
+    }
+    if (stereo) launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
+    else launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
+    return true;
+}
+
+template <int H>
+void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                     const double *win, hipStream_t st) {
+    const uint32_t lanes = nframes * p.ncand;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 4>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
+                       frame0, nframes, n, win);
+}
+}  // namespace
+
+namespace flacgpu_k {
+void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                       const double *win, hipStream_t st) {
+    if (try_autocorr3(p, frame0, nframes, n, win, st)) return;
+    switch (H) {
+    case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
+    case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;
+    case 12: launch_autocorr<12>(p, frame0, nframes, n, win, st); break;
+    case 16: launch_autocorr<16>(p, frame0, nframes, n, win, st); break;
+    case 20: launch_autocorr<20>(p, frame0, nframes, n, win, st); break;
+    case 24: launch_autocorr<24>(p, frame0, nframes, n, win, st); break;
+    case 28: launch_autocorr<28>(p, frame0, nframes, n, win, st); break;
+    case 32: launch_autocorr<32>(p, frame0, nframes, n, win, st); break;
+    default: launch_autocorr<36>(p, frame0, nframes, n, win, st); break;
+    }
+}
+void launch_autocorr_mfma(const Params &p, uint32_t blocks, uint32_t n, const double *win, double *ac,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_autocorr_mfma, dim3(blocks), dim3(WG), 0, st, p, n, win, ac);
+}
+}  // namespace flacgpu_k

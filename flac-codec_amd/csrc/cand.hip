@@ -1,0 +1,26 @@
+// cand.hip -- K2+K5 wave kernel k_cand64: FIXED + LPC + Rice search + choice of one candidate per wave.
+// One of the translation units of libflacenc_amd.so (gfx950 only; built with -ffp-contract=off, see
+// Makefile); the kernels are reached through the launchers declared in kernels/types.h.
+#include "kernels/types.h"
+
+#include <stdlib.h>
+
+namespace {
+#include "kernels/common.inc"
+#include "kernels/wave_cand.inc"
+}  // namespace
+
+namespace flacgpu_k {
+void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+    if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks only
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 32>), dim3(blocks), dim3(WG), 0, st, p);
+        return;
+    }
+    switch (B) {
+#define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl, 16>), dim3(blocks), dim3(WG), 0, st, p); break;
+        FLACGPU_WAVE_SIZES(X)
+#undef X
+    default: break;
+    }
+}
+}  // namespace flacgpu_k

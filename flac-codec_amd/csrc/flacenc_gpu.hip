@@ -5,8 +5,10 @@
 // -ffp-contract=off is REQUIRED: the f64 analysis must round exactly like the
 // reference (Rust never contracts a*b+c; it uses mul_add only where written).
 //
-// One translation unit; the kernels live in kernels/*.inc (included below inside the anonymous
-// namespace), this file holds the context, the launch helpers and the C ABI (include/flacenc_gpu.h).
+// The kernels live in kernels/*.inc; the large families are compiled as translation units of their
+// own (cand.hip, pack.hip, autocorr.hip, lpc.hip, decode.hip -- parallel build) and reached through
+// the launchers of kernels/types.h.  This file holds the context, the small kernels and the C ABI
+// (include/flacenc_gpu.h).
 //
 // Kernel inventory (reference function each one replaces, /root/reference/src):
 //   K0    k_deinterleave2 / k_deinterleave_n / k_deinterleave + k_orbits, k_candinfo (k0_split.inc)
@@ -26,7 +28,7 @@
 //           stream.rs:242-276, 1390-1413, 1603-1619; encode.rs:3078-3135, 3834-3907, 2408-2409;
 //         generic: k_zero + k_pack + k_crc
 //   N3    k_decode (decode.inc)  decode.rs:1388-1856 read_frame .. predict, one lane per subframe
-#include <hip/hip_runtime.h>
+#include "kernels/types.h"
 
 #include <math.h>
 #include <stdint.h>
@@ -40,21 +42,16 @@
 #include <type_traits>
 #include <vector>
 
-#include "flacenc_gpu.h"
+thread_local std::string g_last_error;
 
 namespace {
 #include "kernels/common.inc"
 #include "kernels/k0_split.inc"
 #include "kernels/generic_analysis.inc"
-#include "kernels/autocorr.inc"
-#include "kernels/lpc.inc"
 #include "kernels/generic_fir.inc"
-#include "kernels/wave_cand.inc"
 #include "kernels/decide_emit.inc"
-#include "kernels/pack.inc"
-#include "kernels/decode.inc"
-
 }  // namespace
+using namespace flacgpu_k;
 
 struct flacgpu_ctx;
 static int ctx_sync(flacgpu_ctx *c);
@@ -209,16 +206,11 @@ bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_fram
     return false;
 }
 
-void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st) {
-    if (p.max_lpc_order <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<8>), dim3(blocks), dim3(64), 0, st, p);
-    else if (p.max_lpc_order <= 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<12>), dim3(blocks), dim3(64), 0, st, p);
-    else if (p.max_lpc_order <= 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<16>), dim3(blocks), dim3(64), 0, st, p);
-    else if (getenv("FLACGPU_LPC_DYN")) hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<32>), dim3(blocks), dim3(64), 0, st, p);
-}
+const char *const kKernelNames[FLACGPU_N_KERNELS] = {
+    "k_deinterleave", "k_stereo_stats", "k_fixed", "k_autocorr", "k_lpc",
+    "k_fir",          "k_decide",       "k_emit",  "k_layout",   "k_pack",
+    "k_crc",          "k_cand64"};
 
-// block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
-#define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
 bool wave_block_size(uint32_t B) {
     switch (B) {
 #define X(n, spl) case n:
@@ -226,137 +218,6 @@ bool wave_block_size(uint32_t B) {
 #undef X
         return true;
     default: return false;
-    }
-}
-void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
-    if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks only
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 32>), dim3(blocks), dim3(WG), 0, st, p);
-        return;
-    }
-    switch (B) {
-#define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl, 16>), dim3(blocks), dim3(WG), 0, st, p); break;
-        FLACGPU_WAVE_SIZES(X)
-#undef X
-    default: break;
-    }
-}
-template <int NT, int SPL, int MAXO = 16>
-void launch_frame64_nt(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
-    static bool big_lds = false;  // frames of 5..8 channels need more than the default 64 KB
-    if (lds > 64 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute((const void *)k_frame64<NT, SPL, MAXO>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        big_lds = true;
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_frame64<NT, SPL, MAXO>), dim3(frames), dim3(NT), lds, st, p, q);
-}
-template <int SPL>
-void launch_frame64_spl(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
-    switch (p.channels) {
-    case 1: launch_frame64_nt<64, SPL>(p, q, frames, lds, st); break;
-    case 2: launch_frame64_nt<128, SPL>(p, q, frames, lds, st); break;
-    case 3: launch_frame64_nt<192, SPL>(p, q, frames, lds, st); break;
-    case 4: launch_frame64_nt<256, SPL>(p, q, frames, lds, st); break;
-    default:
-        if constexpr (SPL == 64) {  // 5..8 channels: 4096-sample frames only
-            switch (p.channels) {
-            case 5: launch_frame64_nt<320, SPL>(p, q, frames, lds, st); break;
-            case 6: launch_frame64_nt<384, SPL>(p, q, frames, lds, st); break;
-            case 7: launch_frame64_nt<448, SPL>(p, q, frames, lds, st); break;
-            default: launch_frame64_nt<512, SPL>(p, q, frames, lds, st); break;
-            }
-        }
-        break;
-    }
-}
-void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
-    if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks, <= 4 channels
-        switch (p.channels) {
-        case 1: launch_frame64_nt<64, 64, 32>(p, q, frames, lds, st); break;
-        case 2: launch_frame64_nt<128, 64, 32>(p, q, frames, lds, st); break;
-        case 3: launch_frame64_nt<192, 64, 32>(p, q, frames, lds, st); break;
-        default: launch_frame64_nt<256, 64, 32>(p, q, frames, lds, st); break;
-        }
-        return;
-    }
-    switch (B) {
-#define X(n, spl) case n: launch_frame64_spl<spl>(p, q, frames, lds, st); break;
-        FLACGPU_WAVE_SIZES(X)
-#undef X
-    default: break;
-    }
-}
-
-template <int NL, bool STEREO>
-void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
-                      const double *win, hipStream_t st) {
-    const uint32_t groups = (nframes * p.ncand + 63) / 64;
-    // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
-    // SIMD to issue at full rate and 8192 frames are only 512 candidate groups (0.23 ms against
-    // 0.31 ms split 2 ways).  When other contexts keep the SIMDs busy anyway, the 2-way split wins:
-    // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
-    // instructions).
-    if (p.ac_split == 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
-                           frame0, nframes, n, win);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
-                           frame0, nframes, n, win);
-}
-template <bool STEREO>
-void launch_autocorr3_nl(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
-                         hipStream_t st) {
-    const uint32_t nl = p.max_lpc_order + 1;
-    if (nl <= 5) launch_autocorr3<5, STEREO>(p, frame0, nframes, n, win, st);
-    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, frame0, nframes, n, win, st);
-    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, frame0, nframes, n, win, st);
-    else launch_autocorr3<17, STEREO>(p, frame0, nframes, n, win, st);
-}
-// frame length a multiple of 32, order <= 16, and either stereo L/R/M/S candidates of <= 24-bit
-// samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
-bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
-                   hipStream_t st) {
-    if (n < 32 || n % 32 != 0 || getenv("FLACGPU_NO_AC3")) return false;
-    const bool stereo = p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24;
-    const bool indep = !p.stereo4 && p.ncand == p.channels;
-    if (!stereo && !indep) return false;
-    if (p.max_lpc_order > 16) {  // lags up to 32: two blocks of history, frame a multiple of 64
-        if (n % 64 != 0) return false;
-        const uint32_t groups = (nframes * p.ncand + 63) / 64;
-        if (stereo)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
-                               nframes, n, win);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
-                               nframes, n, win);
-        return true;
-    }
-    if (stereo) launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
-    else launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
-    return true;
-}
-
-template <int H>
-void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
-                     const double *win, hipStream_t st) {
-    const uint32_t lanes = nframes * p.ncand;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr2<H, 4>), dim3((lanes + 63) / 64), dim3(WG), 0, st, p,
-                       frame0, nframes, n, win);
-}
-
-void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
-                       const double *win, hipStream_t st) {
-    if (try_autocorr3(p, frame0, nframes, n, win, st)) return;
-    switch (H) {
-    case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
-    case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;
-    case 12: launch_autocorr<12>(p, frame0, nframes, n, win, st); break;
-    case 16: launch_autocorr<16>(p, frame0, nframes, n, win, st); break;
-    case 20: launch_autocorr<20>(p, frame0, nframes, n, win, st); break;
-    case 24: launch_autocorr<24>(p, frame0, nframes, n, win, st); break;
-    case 28: launch_autocorr<28>(p, frame0, nframes, n, win, st); break;
-    case 32: launch_autocorr<32>(p, frame0, nframes, n, win, st); break;
-    default: launch_autocorr<36>(p, frame0, nframes, n, win, st); break;
     }
 }
 
@@ -442,8 +303,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(pack_lds_bytes((uint32_t)B))));
+    HIP_TRY(pack_set_attributes(pack_lds_bytes((uint32_t)B)));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
     *out = c;
@@ -700,7 +560,7 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     q.cap_bytes = c->packed_cap;
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
     if (c->timing) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
+    launch_layout(p, q, st);
     // frames of a wave block length are assembled whole in LDS by k_frame64 (residuals recomputed
     // from the PCM, CRC-16 from LDS, one write of the finished bytes); any other frame goes
     // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
@@ -722,7 +582,7 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = p.n_frames - n_fast;
-    if (pg.fcount) hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, p.n_frames);
+    if (pg.fcount) launch_zero(q, p.n_frames, st);
     if (c->timing) (void)hipEventRecord(ev[1], st);
     if (pf.fcount) launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
     if (pg.fcount) {
@@ -730,14 +590,14 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
             hipLaunchKernelGGL(k_emit, dim3(pg.fcount * p.channels), dim3(WG),
                                (size_t)p.block_size * sizeof(int32_t), st, pg);
         }
-        hipLaunchKernelGGL(k_pack, dim3(pg.fcount * p.channels), dim3(WG), pack_lds_bytes(p.block_size), st, pg, q);
+        launch_pack(pg, q, pg.fcount * p.channels, pack_lds_bytes(p.block_size), st);
     }
     if (c->timing) (void)hipEventRecord(ev[2], st);
     {   // CRC-16 of the frames that did not take the fused kernel
         Params pc = p;
         pc.f0 = fused ? n_fast : 0;
         pc.fcount = p.n_frames - pc.f0;
-        if (pc.fcount) hipLaunchKernelGGL(k_crc<false>, dim3(pc.fcount), dim3(WG), 0, st, pc, q, (uint32_t *)nullptr);
+        if (pc.fcount) launch_crc(false, pc, q, pc.fcount, nullptr, st);
     }
     if (c->timing) (void)hipEventRecord(ev[3], st);
     HIP_TRY(hipGetLastError());
@@ -832,7 +692,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's
         if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
-        hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, r, q);
+        launch_layout(r, q, st);
         if (!half) HIP_TRY(hipEventRecord(c->ev_layout, st));
         launch_frame64(r, q, B, r.fcount, l64, st);
     }
@@ -908,11 +768,10 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
     // warm-up + timed launch of the MFMA kernel, writing into the regular ac buffer
     for (int it = 0; it < 2; it++) {
         if (it == 1) (void)hipEventRecord(c->ev[0], st);
-        hipLaunchKernelGGL(k_autocorr_mfma, dim3((unsigned)((nc + 3) / 4)), dim3(WG), 0, st, p,
-                           p.block_size, c->d_window_full, c->d_ac);
+        launch_autocorr_mfma(p, (uint32_t)((nc + 3) / 4), p.block_size, c->d_window_full, c->d_ac, st);
         if (it == 1) (void)hipEventRecord(c->ev[1], st);
     }
-    hipLaunchKernelGGL(k_lpc, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, st, p);
+    launch_lpc_generic(p, (uint32_t)((nc + 63) / 64), st);
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
@@ -973,27 +832,17 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     // it runs beside it on the context's second stream
     HIP_TRY(hipEventRecord(c->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    hipLaunchKernelGGL(k_crc<true>, dim3(p.n_frames), dim3(WG), 0, c->aux_stream, p, q, c->d_verify);
+    launch_crc(true, p, q, p.n_frames, c->d_verify, c->aux_stream);
     HIP_TRY(hipEventRecord(c->ev_join, c->aux_stream));
     {
-        // One lane per subframe.  Every lane reads and writes its own cache lines, so the limit is
-        // the CU's address path (lines per instruction x waves per CU), not the SIMD: measured on
-        // 4096 / 8192 / 32768 stereo frames, 32-lane waves win over 64 (fewer lines per
-        // instruction) and over 16 or 8 (fewer waves per CU): 1.17 / 1.44 / 2.93 ms.
         const uint32_t units = p.n_frames * p.channels;
         uint32_t lanes = 32;
         if (const char *e = getenv("FLACGPU_DECODE_LANES")) {  // experiment knob
             const uint32_t v = (uint32_t)atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lanes = v;
         }
-        const dim3 grid((units + lanes - 1) / lanes), block(lanes);
-        const uint32_t mo = c->opts.max_lpc_order;  // FIXED needs 4; the ring is also the store batch
-        if (mo <= 8) hipLaunchKernelGGL(k_decode<8>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
-        else if (mo <= 12) hipLaunchKernelGGL(k_decode<12>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
-        else if (mo <= 16) hipLaunchKernelGGL(k_decode<16>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
-        else hipLaunchKernelGGL(k_decode<32>, grid, block, 0, st, pd, q, c->d_decoded, c->d_verify);
-        hipLaunchKernelGGL(k_decode_finish, dim3(p.n_frames), dim3(WG), 0, st, pd, c->d_decoded, expect,
-                           c->d_verify);
+        launch_decode(c->opts.max_lpc_order, units, lanes, pd, q, c->d_decoded, c->d_verify, st);
+        launch_decode_finish(pd, c->d_decoded, expect, c->d_verify, st);
     }
     HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     (void)hipEventRecord(c->ev[1], st);

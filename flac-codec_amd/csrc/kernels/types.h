@@ -1,0 +1,140 @@
+// types.h -- records, kernel parameters and launcher declarations shared by the translation units
+// of libflacenc_amd.so.  The kernels are split over several .hip files only so that they compile in
+// parallel; every kernel lives in an anonymous namespace of its own file and is reached through
+// the launchers declared at the end of this header.
+#ifndef FLACGPU_KERNEL_TYPES_H
+#define FLACGPU_KERNEL_TYPES_H
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include <string>
+
+#include "flacenc_gpu.h"
+
+
+constexpr int WG = 256;          // threads per workgroup (4 wave64)
+constexpr int MAXP = 6;          // max effective partition order (64 partitions, encode.rs:3756)
+constexpr int NLEAF = 1 << MAXP;
+constexpr int NNODE = 2 * NLEAF - 1;
+
+extern thread_local std::string g_last_error;  // defined in flacenc_gpu.hip
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return FLACGPU_ERR_HIP;                                                     \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------
+// device-side records
+// ---------------------------------------------------------------------------------
+typedef flacgpu_subframe_plan SubPlan;  // same layout on both sides of the ABI
+
+struct CandInfo {        // per (frame, candidate)
+    uint8_t active;      // 0: not a candidate for this frame (fast correlation / no mid)
+    uint8_t wasted;
+    uint8_t bps;         // effective bps after wasted-bit removal
+    uint8_t is_const;    // all samples zero -> CONSTANT, nothing else to analyse
+};
+
+struct LpcParams {       // per (frame, candidate), output of k_lpc
+    int32_t status;      // 0 ok; else the reference's error (1 Insufficient, 2 NoBestOrder,
+                         // 3 ZeroCoeffs, 4 NegativeShift)
+    uint8_t order, precision, shift, pad;
+    int32_t qlp[FLACGPU_MAX_LPC_ORDER];
+};
+
+struct FrameInfo {       // per frame, from k_stereo_stats (fast mode) -- preset assignment
+    uint8_t assignment;
+    uint8_t pad[3];
+};
+
+struct Params {
+    // stream shape / options
+    uint32_t channels, bps, block_size, ldb;      // ldb = row stride of the planar buffer
+    uint32_t ncand;                                // candidate slots per frame
+    uint32_t stereo4;                              // 1: slots are L,R,M,S
+    uint32_t mid_side, exhaustive;
+    uint32_t max_lpc_order, max_po, use_rice2;
+    uint32_t n_frames, last_len;
+    uint32_t f0, fcount;                           // frames [f0, f0 + fcount) handled by this launch
+    uint32_t ac_split;                             // waves the lags of k_autocorr3 are split over (2 or 4)
+    // buffers
+    const int32_t *planar;
+    const double *window_full, *window_last;
+    const double *log2_thr;                        // [128], index e + 64
+    CandInfo *cinfo;
+    SubPlan *fixed_plan, *cand_plan, *out_plan;
+    LpcParams *lpc;
+    double *ac;                                    // [n_frames*ncand][36]
+    FrameInfo *finfo;
+    flacgpu_frame_plan *frame_plan;
+    int32_t *residuals;                            // [n_frames][channels][block_size]
+    uint32_t *stats;                               // [4]
+};
+
+
+constexpr int AC_LD = 36;        // row stride of the ac buffer (max lag group count rounded up)
+constexpr uint32_t FN = 4096;    // the block length of every preset but `fast`
+
+struct PackParams {
+    uint64_t first_frame_number;
+    uint32_t sample_rate;
+    uint32_t *out_words;      // packed bytes, viewed as big-endian-filled 32-bit words
+    uint64_t *frame_off;      // [n_frames + 1] byte offsets
+    uint64_t cap_bytes;
+};
+
+// words reserved for a subframe's bit string: a chosen subframe is never longer than its
+// VERBATIM form (<= 40 + 33 n bits) plus the 16-byte frame header; multiple of 4 words
+__host__ __device__ constexpr uint32_t pack_sb_words(uint32_t block_size) {
+    return ((block_size * 33u / 32u + 32u) + 3u) & ~3u;
+}
+
+// words of LDS a whole frame of 4096-sample subframes may need (VERBATIM everywhere + header +
+// CRC-16 + one guard word for the funnel shifts); multiple of 4 words
+__host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_t bps, uint32_t n = FN) {
+    return (((16u + 2u) * 8u + channels * (n * (bps + 1u) + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
+}
+
+
+// block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
+#define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
+
+// ---- launchers (one per kernel family; defined in the .hip file that holds the kernels) ----
+namespace flacgpu_k {
+// lpc.hip
+void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st);
+void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
+// cand.hip
+void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
+// autocorr.hip
+void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+                       const double *win, hipStream_t st);
+void launch_autocorr_mfma(const Params &p, uint32_t blocks, uint32_t n, const double *win, double *ac,
+                          hipStream_t st);
+// pack.hip
+void launch_layout(const Params &p, const PackParams &q, hipStream_t st);
+void launch_zero(const PackParams &q, uint32_t n_frames, hipStream_t st);
+void launch_pack(const Params &p, const PackParams &q, uint32_t blocks, size_t lds, hipStream_t st);
+void launch_crc(bool verify, const Params &p, const PackParams &q, uint32_t frames, uint32_t *verify_counts,
+                hipStream_t st);
+void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds,
+                    hipStream_t st);
+hipError_t pack_set_attributes(size_t pack_lds);
+// frame64_a.hip / frame64_b.hip / frame64_c.hip
+void launch_frame64_4096(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
+void launch_frame64_deep(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
+void launch_frame64_short(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds,
+                          hipStream_t st);
+// decode.hip
+void launch_decode(uint32_t max_lpc_order, uint32_t units, uint32_t lanes, const Params &p, const PackParams &q,
+                   int32_t *decoded, uint32_t *verify_counts, hipStream_t st);
+void launch_decode_finish(const Params &p, int32_t *decoded, const int32_t *expect, uint32_t *verify_counts,
+                          hipStream_t st);
+}  // namespace flacgpu_k
+#endif

@@ -1,0 +1,42 @@
+// pack.hip -- K8 k_layout, generic K9+K10 k_zero + k_pack + k_crc, and the dispatch of the wave-per-subframe
+// k_frame64 (instantiated in frame64_a/b/c.hip): stream.rs:242-276, 1390-1413, 1603-1619; encode.rs:3078-3135,
+// 3834-3907, 2408-2409; crc.rs:99-188.
+// One of the translation units of libflacenc_amd.so (gfx950 only; built with -ffp-contract=off, see
+// Makefile); the kernels are reached through the launchers declared in kernels/types.h.
+#include "kernels/types.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+#include "kernels/common.inc"
+#include "kernels/wave_cand.inc"
+#include "kernels/pack.inc"
+
+}  // namespace
+
+namespace flacgpu_k {
+void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
+    if (p.max_lpc_order > 16) launch_frame64_deep(p, q, frames, lds, st);   // 4096-sample blocks, <= 4 channels
+    else if (B == FN) launch_frame64_4096(p, q, frames, lds, st);
+    else launch_frame64_short(p, q, B, frames, lds, st);                   // <= 4 channels
+}
+void launch_layout(const Params &p, const PackParams &q, hipStream_t st) {
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
+}
+void launch_zero(const PackParams &q, uint32_t n_frames, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, n_frames);
+}
+void launch_pack(const Params &p, const PackParams &q, uint32_t blocks, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(WG), lds, st, p, q);
+}
+void launch_crc(bool verify, const Params &p, const PackParams &q, uint32_t frames, uint32_t *verify_counts,
+                hipStream_t st) {
+    if (verify) hipLaunchKernelGGL(k_crc<true>, dim3(frames), dim3(WG), 0, st, p, q, verify_counts);
+    else hipLaunchKernelGGL(k_crc<false>, dim3(frames), dim3(WG), 0, st, p, q, verify_counts);
+}
+hipError_t pack_set_attributes(size_t pack_lds) {
+    return hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds);
+}
+}  // namespace flacgpu_k
