@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=3, choices=(1, 2, 3, 4),
                     help="encoder contexts consecutive batches rotate through (multi-buffering)")
+    ap.add_argument("--lag-split", type=int, default=0, choices=(0, 2, 4),
+                    help="waves the autocorrelation lags are split over (0: the library default)")
     args = ap.parse_args()
 
     import torch
@@ -90,9 +92,9 @@ def main():
     for _ in range(args.contexts - 1):
         ans.append(GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
                                device=local_rank))
-    if len(ans) > 1:
-        for a in ans:   # the SIMDs are kept busy by the other contexts: fewer instructions win
-            a.set_tuning(a.TUNE_LAG_SPLIT, 2)
+    if args.lag_split:
+        for a in ans:
+            a.set_tuning(a.TUNE_LAG_SPLIT, args.lag_split)
     streams = [torch.cuda.Stream() for _ in ans]
     step_no = [0]
 
