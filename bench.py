@@ -10,15 +10,23 @@ resident in HBM (interleaved int32, the layout FlacSampleWriter::write receives)
 de-interleave -> fixed/LPC analysis -> channel-assignment decision -> residuals -> frame
 assembly (headers, Rice bit-packing, CRC-8/16) -> finished FLAC frame bytes in HBM.
 Stream bookkeeping that the reference keeps per stream on the host (MD5 of the PCM,
-metadata rewrite) is outside the step; DESIGN.md states its cost and the PCIe-inclusive rate.
+metadata rewrite) is outside the step; the `end_to_end` block of the output line measures the
+whole host PCM -> .flac bytes path (PCIe, MD5, container included) separately.
 
-Usage:  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torchrun)
+Usage:  python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}]
+  N > 1 without WORLD_SIZE in the environment: this process starts N ranks of itself (one per
+  GPU, before it touches any GPU) and relays rank 0's line; under torchrun the ranks are taken
+  from the environment and --gpus must equal WORLD_SIZE.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,21 +36,189 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 BLOCK = 4096
-CHANNELS = 2
-BPS = 24
-RATE = 48000
-MAX_LPC = 12
-MAX_PO = 6
-FRAMES = 8192          # 8192 blocks x 4096
-DISTINCT = 512         # distinct synthetic frames, tiled to FRAMES
+FRAMES = 8192          # 8192 blocks x 4096 per GPU
+DISTINCT = 512         # distinct synthetic frames, tiled to FRAMES (all of them are oracle-checked)
+
+# SURVEY.md section 0 (level mapping) + 8(d) (configs -> inputs)
+CONFIGS = {
+    2: dict(rate=48000, bps=16, ch=2, lpc=0, po=5, level="L5-fixed",
+            text="48 kHz/16-bit stereo, blocksize 4096, level 5 with fixed predictors only "
+                 "(Options::default().max_lpc_order(None): partition order 5, mid-side, exhaustive)"),
+    3: dict(rate=48000, bps=24, ch=2, lpc=12, po=6, level="L8",
+            text="48 kHz/24-bit stereo, blocksize 4096, level 8 (Options::best: LPC order 12, "
+                 "partition order 6, mid-side, exhaustive)"),
+    4: dict(rate=192000, bps=24, ch=8, lpc=12, po=6, level="L8",
+            text="192 kHz/24-bit 8-channel, blocksize 4096, level 8 (Options::best), contiguous frame "
+                 "ranges per GPU"),
+    5: dict(rate=96000, bps=24, ch=2, lpc=32, po=6, level="L8x",
+            text="96 kHz/24-bit stereo, blocksize 4096, level 8 exhaustive (Options::best + LPC order "
+                 "32, partition order 6)"),
+}
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4   # wave64 instructions / s at the nominal clock
 
 
-def make_pcm(seed, frames):
+def make_pcm(seed, frames, channels, bps):
     from _pcm import synth_fast
 
-    base = synth_fast(seed, CHANNELS, BPS, BLOCK * min(DISTINCT, frames))
+    base = synth_fast(seed, channels, bps, BLOCK * min(DISTINCT, frames))
     reps = (frames + DISTINCT - 1) // DISTINCT
-    return np.tile(base, reps)[: frames * BLOCK * CHANNELS]
+    return np.tile(base, reps)[: frames * BLOCK * channels]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """--gpus N without torchrun: N children of this script, one per GPU.  Nothing in this
+    (parent) process touches a GPU: device_count() does not initialise one."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} asked for, but this box has {have} GPU(s); "
+                         f"refusing to report a line for fewer ranks than requested\n")
+        sys.exit(2)
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def orc_options(orc, cfg):
+    oo = orc.options("best" if cfg["lpc"] >= 12 else "default")
+    return oo.copy(max_lpc_order=cfg["lpc"], max_partition_order=cfg["po"])
+
+
+def cpu_baseline(orc, cfg, pcm, frames_total):
+    """The oracle (C restatement of the reference, NOT the Rust binary) on this box's host cores:
+    median of 5 runs after one warm-up, each on a bounded sample of the same workload."""
+    C = cfg["ch"]
+    oo = orc_options(orc, cfg)
+
+    def run(frames, threads):
+        sample = pcm[: frames * BLOCK * C]
+        times = []
+        ref = None
+        for i in range(6):
+            t = time.perf_counter()
+            rc, out, _ = orc.encode_stream(oo, cfg["rate"], cfg["bps"], C, sample, total_known=True,
+                                           threads=threads)
+            dt = time.perf_counter() - t
+            assert rc == 0
+            if ref is None:
+                ref = out
+            assert out == ref
+            if i:
+                times.append(dt)
+        return sample.size / statistics.median(times) / 1e6, frames
+
+    per_frame = BLOCK * C
+    f1 = max(64, min(frames_total, int(2048 * 8192 / per_frame)))
+    fn = max(64, min(frames_total, int(4096 * 8192 / per_frame)))
+    ncores = os.cpu_count() or 1
+    v1, n1 = run(f1, 1)
+    v4, n4 = run(fn, 4)
+    va, na = run(fn, ncores)
+    return {"value": round(v1, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"first {n1} frames of the bench batch, full encode to an in-memory .flac "
+                      f"(MD5 + analysis + bit-pack + CRC), 1 thread, median of 5 after 1 warm-up",
+            "four_threads": {"value": round(v4, 3), "cores": 4, "frames": n4,
+                             "note": "frame-parallel restatement on 4 threads: an upper bound of the "
+                                     "reference's per-frame fork-join (at most 4 concurrent tasks per "
+                                     "stereo frame, frames sequential; encode.rs:2690-2745, 2906-2928)"},
+            "all_cores_frame_parallel": {"value": round(va, 3), "cores": ncores, "frames": na,
+                                         "note": "not something the reference does"}}
+
+
+def end_to_end(cfg, pcm, device, orc):
+    """Host-resident PCM -> finished .flac bytes in host memory through the public writer surface
+    (FlacSampleWriter::new / write / finalize, encode.rs:487-627): H2D, kernels, D2H, MD5, seek
+    table and metadata rewrite included.  One stream, then many concurrent streams sharing the GPU."""
+    from flac_codec_amd.encode import FlacSampleWriter, Options
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    C, bps, rate = cfg["ch"], cfg["bps"], cfg["rate"]
+
+    def opts():
+        o = Options.best() if cfg["lpc"] >= 12 else Options.default()
+        return o.max_lpc_order(cfg["lpc"] or None).max_partition_order(cfg["po"]).device(device)
+
+    def encode(samples):
+        w = FlacSampleWriter(None, opts(), rate, bps, C, samples.size)
+        w.write(samples)
+        w.finalize()
+        data = w.getvalue()
+        st = w.stats()
+        w.close()
+        return data, st
+
+    out = {}
+    # one stream: 2048 blocks (~3 minutes of 48 kHz audio)
+    one = pcm[: 2048 * BLOCK * C]
+    encode(one[: 64 * BLOCK * C])           # warm-up (context creation, staging buffers)
+    times = []
+    st = None
+    for _ in range(5):
+        t = time.perf_counter()
+        _, st = encode(one)
+        times.append(time.perf_counter() - t)
+    rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, one[: 256 * BLOCK * C],
+                                   total_known=True)
+    small, _ = encode(one[: 256 * BLOCK * C])
+    assert rc == 0 and small == ref, "end-to-end stream differs from the oracle's .flac"
+    dt = statistics.median(times)
+    md5_rate = one.size / (st.md5_ms * 1e-3) / 1e6 if st.md5_ms > 0 else None
+    out["one_stream"] = {"Msamples/s": round(one.size / dt / 1e6, 1), "frames": 2048,
+                         "md5_thread_Msamples/s": round(md5_rate, 1) if md5_rate else None,
+                         "byte_identical_to_oracle": True,
+                         "note": "median of 5; the stream MD5 is a serial chain on one host thread "
+                                 "(encode.rs:571, 1292-1318) and caps a single stream"}
+    # many streams: one writer per thread, every stream 512 blocks
+    n_streams = 64
+    per = pcm[: 512 * BLOCK * C]
+    results = [None] * n_streams
+
+    def worker(i):
+        results[i] = encode(per)[0]
+
+    best = None
+    for _ in range(3):
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(n_streams)]
+        t = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    assert all(r == results[0] for r in results)
+    out["many_streams"] = {"Msamples/s": round(n_streams * per.size / best / 1e6, 1), "streams": n_streams,
+                           "frames_per_stream": 512, "host_cores": os.cpu_count(),
+                           "note": "best of 3; one writer per host thread, contexts pooled"}
+    # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
+    an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
+    batch = pcm[: 1024 * BLOCK * C]
+    an.encode_frames(batch, 1024, BLOCK, 0, rate)
+    times = []
+    for _ in range(5):
+        t = time.perf_counter()
+        an.encode_frames(batch, 1024, BLOCK, 0, rate)
+        times.append(time.perf_counter() - t)
+    an.close()
+    out["encode_frames_pcie_inclusive"] = {
+        "Msamples/s": round(batch.size / statistics.median(times) / 1e6, 1), "frames": 1024,
+        "note": "flacgpu_encode_frames, one context, synchronous: H2D + kernels + D2H"}
+    return out
 
 
 def main():
@@ -50,21 +226,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (SURVEY.md 8(d)); 3 is the headline metric")
     ap.add_argument("--frames", type=int, default=FRAMES, help="FLAC frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--contexts", type=int, default=3, choices=(1, 2, 3, 4),
                     help="encoder contexts consecutive batches rotate through (multi-buffering)")
     ap.add_argument("--lag-split", type=int, default=0, choices=(0, 2, 4),
                     help="waves the autocorrelation lags are split over (0: the library default)")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps run before the warm-up until this much wall time has passed "
+                         "(the clocks of an idle GPU take longer to ramp than a few batches)")
+    ap.add_argument("--sustained-steps", type=int, default=200,
+                    help="steps of the additional long timed loop reported as `sustained`")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}\n")
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -77,21 +265,20 @@ def main():
     from flac_codec_amd.gpu import GpuAnalyzer
     from flac_codec_amd.parallel import gather_shard_counters
 
+    cfg = CONFIGS[args.config]
+    C, BPS, RATE, MAX_LPC, MAX_PO = cfg["ch"], cfg["bps"], cfg["rate"], cfg["lpc"], cfg["po"]
     F = args.frames
-    pcm = make_pcm(1000 + rank, F)                 # every rank encodes its own frame range
+    pcm = make_pcm(1000 + 16 * args.config + rank, F, C, BPS)   # every rank encodes its own frame range
     d_pcm = torch.from_numpy(pcm).cuda()
-    an = GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
-                     device=local_rank)
     first_frame = rank * F                          # contiguous frame ranges per GPU (8(e))
     # Multi-buffering, as a streaming encoder runs: consecutive batches rotate through a few
     # encoder contexts (each with its own plans / output buffer in HBM) on their own HIP streams,
     # so the HBM-bound, latency-bound and VALU-bound kernels of neighbouring batches overlap; a
     # context's output stays valid until the context is used again.  --contexts 1 runs every
     # batch back to back on one context.
-    ans = [an]
-    for _ in range(args.contexts - 1):
-        ans.append(GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, CHANNELS, max_frames=F,
-                               device=local_rank))
+    ans = [GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, C, max_frames=F, device=local_rank)
+           for _ in range(args.contexts)]
+    an = ans[0]
     if args.lag_split:
         for a in ans:
             a.set_tuning(a.TUNE_LAG_SPLIT, args.lag_split)
@@ -101,55 +288,87 @@ def main():
     def step():   # analysis + frame assembly of one whole batch (flacgpu_encode_device)
         i = step_no[0] % len(ans)
         step_no[0] += 1
-        ans[i].encode_device(d_pcm.data_ptr(), F, BLOCK, first_frame, RATE,
-                             stream=streams[i].cuda_stream)
+        ans[i].encode_device(d_pcm.data_ptr(), F, BLOCK, first_frame, RATE, stream=streams[i].cuda_stream)
 
+    def timed(k):
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    t_pre = time.perf_counter()
+    prewarm_steps = 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        prewarm_steps += 8
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)
+    samples_per_step = F * BLOCK * C * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    sustained = None
+    if args.sustained_steps > 0:
+        el = timed(args.sustained_steps)
+        sustained = {"steps": args.sustained_steps, "ms_per_step": round(el / args.sustained_steps * 1e3, 4),
+                     "value": round(samples_per_step * args.sustained_steps / el / 1e6, 2), "unit": "Msamples/s"}
     # per-shard counters (frames, bytes, min/max frame size) gathered over RCCL: the only
     # cross-GPU exchange of the path (seek-table offsets / STREAMINFO)
     counters = gather_shard_counters(an, F, dist)
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    samples_per_step = F * BLOCK * CHANNELS * world
-    value = samples_per_step * args.steps / elapsed / 1e6
-    ms_per_step = elapsed / args.steps * 1e3
+    # ---- parity precondition on this very batch, on EVERY rank: all distinct frames
+    # byte-identical to the oracle, every frame of the batch round-tripped on the device
+    import _oracle as orc
+    from _compare import orc_options_for
+
+    data, off = an.fetch_frames(F)
+    oopts = orc_options_for(BLOCK, MAX_PO, MAX_LPC, True, True)
+    check = min(DISTINCT, F)
+    ok = 1
+    for f in range(check):
+        planar = np.ascontiguousarray(pcm[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
+        rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
+        if rc != 0 or data[off[f]:off[f + 1]] != fb:
+            sys.stderr.write(f"rank {rank}: frame {f} differs from the oracle\n")
+            ok = 0
+            break
+    st = an.stats()
+    if st.order_ties:
+        sys.stderr.write(f"rank {rank}: {st.order_ties} candidates inside the libm-sensitive order band\n")
+    an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+    an.pack_device(first_frame, RATE)
+    vres, vms = an.verify_device(RATE, first_frame)
+    if (vres.bad_structure, vres.bad_crc16, vres.frames_pcm_differs) != (0, 0, 0):
+        ok = 0
+    if dist:
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    assert ok == 1, "parity check failed on at least one rank"
+    compressed_bytes = off[F]
 
     out = None
     if rank == 0:
-        # ---- parity precondition on this very batch: first frames byte-identical to the oracle
-        import _oracle as orc
-        from _compare import orc_options_for
-
-        data, off = an.fetch_frames(F)
-        oopts = orc_options_for(BLOCK, MAX_PO, MAX_LPC, True, True)
-        check = 16
-        for f in range(check):
-            planar = np.ascontiguousarray(
-                pcm[f * BLOCK * CHANNELS:(f + 1) * BLOCK * CHANNELS].reshape(BLOCK, CHANNELS).T)
-            rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
-            assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
-        compressed_bytes = off[F]
-        st = an.stats()
         analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties, "log2_edge": st.log2_edge,
-                          "candidates": 4 * F}
-
-        # ---- per-kernel durations (HIP events on the launch stream), one extra timed pass
+                          "candidates": (4 if C == 2 else C) * F}
+        verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
+                  "Msamples/s": round(F * BLOCK * C / (vms * 1e-3) / 1e6, 1)}
+        # ---- per-kernel durations (HIP events on the launch stream), extra timed passes
         an.set_timing(True)
         reps = 5
         acc = {}
@@ -161,43 +380,38 @@ def main():
             for k, v in {**ms_a, **ms_b}.items():
                 acc[k] = acc.get(k, 0.0) + v / reps
         an.set_timing(False)
-        # device-side decode + CRC verification of the frames just packed (round trip in HBM)
-        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
-        an.pack_device(first_frame, RATE)
-        vres, vms = an.verify_device(RATE, first_frame)
-        assert (vres.bad_structure, vres.bad_crc16, vres.frames_pcm_differs) == (0, 0, 0)
-        verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
-                  "Msamples/s": round(F * BLOCK * CHANNELS / (vms * 1e-3) / 1e6, 1)}
-        # experiment: the same autocorrelation on the f64 matrix cores (NOT bit-exact, not used)
-        an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
-        mf = an.experiment_mfma_autocorr()
-        issued = 4 * F * (BLOCK // 64) * 2 * 2048.0       # MFMAs x 2048 flop (16x16x4 f64)
-        mfma_exp = {"kernel": "k_autocorr_mfma", "ms": round(mf["ms"], 4),
-                    "issued_TFLOP/s": round(issued / (mf["ms"] * 1e-3) / 1e12, 2),
-                    "mfma_util_vs_78.6_TF": round(issued / (mf["ms"] * 1e-3) / 78.6e12, 4),
-                    "max_rel_err_of_a_lag": mf["max_rel_err"],
-                    "candidates_compared": mf["compared"],
-                    "candidates_whose_quantised_lpc_params_change": mf["params_differ"],
-                    "note": "re-associated sums are not the reference's left fold; kept off the product path"}
-        n_cand = 4 * F                      # L, R, M, S per stereo frame
+        mfma_exp = None
+        if 1 <= MAX_LPC <= 16 and C == 2:
+            # experiment: the same autocorrelation on the f64 matrix cores (NOT bit-exact, not used)
+            an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+            mf = an.experiment_mfma_autocorr()
+            issued = 4 * F * (BLOCK // 64) * 2 * 2048.0       # MFMAs x 2048 flop (16x16x4 f64)
+            mfma_exp = {"kernel": "k_autocorr_mfma", "ms": round(mf["ms"], 4),
+                        "issued_TFLOP/s": round(issued / (mf["ms"] * 1e-3) / 1e12, 2),
+                        "mfma_util_vs_78.6_TF": round(issued / (mf["ms"] * 1e-3) / 78.6e12, 4),
+                        "max_rel_err_of_a_lag": mf["max_rel_err"],
+                        "candidates_compared": mf["compared"],
+                        "candidates_whose_quantised_lpc_params_change": mf["params_differ"],
+                        "note": "re-associated sums are not the reference's left fold; kept off the product path"}
+        n_cand = (4 if C == 2 else C) * F          # L, R, M, S per stereo frame; one per channel otherwise
         cand_samples = n_cand * BLOCK
-        # algorithmic bytes / flops per launch (DESIGN.md "Kernels")
+        # algorithmic bytes / flops per launch (DESIGN.md "Kernels"); only kernels
+        # that were launched on this workload appear
         alg = {
-            "k_deinterleave": ("hbm", 8.0 * F * BLOCK * CHANNELS),
-            "k_fixed": ("hbm", 8.0 * cand_samples),
+            "k_deinterleave": ("hbm", 8.0 * F * BLOCK * C),
             "k_autocorr": ("f64", 2.0 * BLOCK * (MAX_LPC + 1) * n_cand),
-            "k_fir": ("hbm", 8.0 * cand_samples),
             # fused FIXED + LPC + Rice search: every candidate's samples are read once, residuals
             # never leave registers, 280-byte plan out
             "k_cand64": ("hbm", 4.0 * cand_samples + 280.0 * n_cand),
-            "k_emit": ("hbm", 8.0 * F * BLOCK * CHANNELS),
-            "k_pack": ("hbm", 4.0 * F * BLOCK * CHANNELS + compressed_bytes),
-            "k_crc": ("hbm", float(compressed_bytes)),
+            # k_frame64 (reported in the k_pack slot): samples in, finished frame bytes out
+            "k_pack": ("hbm", 4.0 * F * BLOCK * C + compressed_bytes),
         }
         kernels = {}
         for k, ms in acc.items():
+            if ms <= 0:
+                continue
             entry = {"ms": round(ms, 4)}
-            if k in alg and ms > 0:
+            if k in alg:
                 kind, amount = alg[k]
                 if kind == "hbm":
                     entry["GB/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
@@ -207,92 +421,46 @@ def main():
         hbm_kernels = {k: v for k, v in kernels.items() if "GB/s" in v}
         dom = max(hbm_kernels, key=lambda k: hbm_kernels[k]["ms"])
         achieved = hbm_kernels[dom]["GB/s"]
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes of this same
-        # command, tools/collect_profiles.sh; corrected as MI355X_MICROARCH.md prescribes)
-        traffic = None
-        traffic_src = None
-        try:
-            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-            if prof and F == FRAMES:
+        # HBM bytes and VALU instructions per launch of the dominant kernel come from the committed
+        # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh; corrected as
+        # MI355X_MICROARCH.md prescribes); they are deterministic for a given input and workload
+        names = {"k_autocorr": "k_autocorr4", "k_deinterleave": "k_deinterleave2", "k_pack": "k_frame64"}
+        traffic = traffic_src = None
+        valu = None
+        if F == FRAMES and args.config == 3:
+            try:
+                key = names.get(dom, dom)
+                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
                 t = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                fast = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr3",
-                        "k_deinterleave": "k_deinterleave2"}
-                key = fast.get(dom, dom) if fast.get(dom, dom) in t else dom
                 if key in t:
                     traffic = t[key]["hbm_bytes"]
                     traffic_src = {"source": "profiles/" + prof[-1], "kernel": key,
                                    "fetch_bytes": t[key].get("fetch_bytes"), "write_bytes": t[key].get("write_bytes")}
-        except Exception:
-            traffic = None
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
-        if dom == "k_cand64":
-            # SURVEY 8(d) prices the stages this kernel fuses separately (K1 FIXED 8 B, K4 FIR 8 B,
-            # K5 Rice search 4 B per candidate sample); the fusion removes all but one 4-byte read.
-            fused = 20.0 * cand_samples
-            roofline["unfused_accounting"] = {
-                "bytes": fused, "equivalent_GB/s": round(fused / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
-                "fir_stage_alone_GB/s": round(8.0 * cand_samples / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
-                "note": "K1 8 B + K4 8 B + K5 4 B per candidate sample (SURVEY 8(d)); `achieved` above "
-                        "counts only the bytes the fused kernel still has to move"}
-        # The integer kernels are bound by VALU instruction issue, not by HBM: one wave64 VALU
-        # instruction holds a SIMD for 4 cycles, so the chip issues at most 1024 SIMDs x clk / 4
-        # wave-instructions per second.  Instruction counts per launch come from the SQ_INSTS_VALU
-        # pass of tools/collect_profiles.sh (deterministic for a given input).
-        try:
-            vprof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_valu.json"))
-            if vprof and F == FRAMES:
+                vprof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_valu.json"))
                 vt = json.load(open(os.path.join(ROOT, "profiles", vprof[-1])))
-                key = {"k_fixed": "k_fixed16", "k_fir": "k_fir16", "k_autocorr": "k_autocorr3",
-                       "k_deinterleave": "k_deinterleave2"}.get(dom, dom)
                 if key in vt and vt[key].get("SQ_INSTS_VALU"):
                     insts = vt[key]["SQ_INSTS_VALU"]
-                    peak_issue = 1024 * 2.4e9 / 4
-                    roofline["valu_issue"] = {
-                        "wave_insts_per_launch": insts, "source": vprof[-1],
-                        "achieved_Ginst/s": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
-                        "peak_Ginst/s": round(peak_issue / 1e9, 1),
-                        "frac": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / peak_issue, 4),
-                        "valu_active_per_wave_cycle": vt[key].get("valu_active_per_wave_cycle")}
-        except Exception:
-            pass
+                    valu = {"wave_insts_per_launch": insts, "source": "profiles/" + vprof[-1],
+                            "achieved_Ginst/s": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
+                            "peak_Ginst/s": round(VALU_ISSUE_PEAK / 1e9, 1),
+                            "frac": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / VALU_ISSUE_PEAK, 4),
+                            "valu_active_per_wave_cycle": vt[key].get("valu_active_per_wave_cycle")}
+            except Exception:
+                pass
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
+        if valu:
+            # the integer kernels are bound by VALU instruction issue, not by HBM
+            roofline["valu_issue"] = valu
 
-        # ---- CPU baseline: the oracle (C restatement of the reference, NOT the Rust binary),
-        # timed on this box's host cores over the same workload
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu_frames = min(F, 4096)
-            sample = pcm[: cpu_frames * BLOCK * CHANNELS]
-            oo = orc.options("best")
-            t1 = time.perf_counter()
-            rc, ref, _ = orc.encode_stream(oo, RATE, BPS, CHANNELS, sample, total_known=True, threads=1)
-            dt1 = time.perf_counter() - t1
-            assert rc == 0
-            ncores = os.cpu_count() or 1
-            t2 = time.perf_counter()
-            rc, ref2, _ = orc.encode_stream(oo, RATE, BPS, CHANNELS, sample, total_known=True,
-                                            threads=ncores)
-            dtn = time.perf_counter() - t2
-            assert ref == ref2
-            # the reference forks at most 4 tasks per stereo frame (L || R, then M || S, each
-            # FIXED || LPC; encode.rs:2690-2745, 2906-2928) and walks frames sequentially: 4
-            # frame-parallel threads of the restatement bound that from above
-            t3 = time.perf_counter()
-            rc, ref3, _ = orc.encode_stream(oo, RATE, BPS, CHANNELS, sample, total_known=True, threads=4)
-            dt4 = time.perf_counter() - t3
-            assert ref == ref3
-            cpu = {"value": round(sample.size / dt1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-                   "kind": "port",
-                   "sample": f"first {cpu_frames} frames of the bench batch, full encode to an "
-                             f"in-memory .flac (MD5 + analysis + bit-pack + CRC), 1 thread",
-                   "four_threads": {"value": round(sample.size / dt4 / 1e6, 3), "cores": 4,
-                                    "note": "upper bound of the reference's per-frame fork-join "
-                                            "(at most 4 concurrent tasks per stereo frame)"},
-                   "all_cores_frame_parallel": {"value": round(sample.size / dtn / 1e6, 3),
-                                                "cores": ncores,
-                                                "note": "not something the reference does"}}
+            cpu = cpu_baseline(orc, cfg, pcm, F)
+        e2e = None
+        if world == 1 and not args.no_end_to_end:
+            e2e = end_to_end(cfg, pcm, local_rank, orc)
         out = {
             "metric": "Msamples/s encode at level 8, 48kHz/24-bit stereo; bit-exact vs reference",
             "value": round(value, 2),
@@ -306,21 +474,24 @@ def main():
             "vs_baseline": None,
             "dtype": "i32/i64 (+f64 LPC analysis)",
             "data": "synthetic",
-            "config": {"workload": "48 kHz/24-bit stereo, blocksize 4096, level 8 (Options::best: "
-                                   "LPC order 12, partition order 6, mid-side, exhaustive), "
-                                   f"{F} frames per GPU per step, PCM resident in HBM, frame bytes "
-                                   f"produced in HBM; consecutive batches rotate through {len(ans)} "
-                                   "encoder context(s) on separate HIP streams",
+            "config": {"workload": f"config {args.config}: {cfg['text']}; {F} frames per GPU per step, PCM "
+                                   f"resident in HBM, frame bytes produced in HBM; consecutive batches rotate "
+                                   f"through {len(ans)} encoder context(s) on separate HIP streams",
+                       "baseline_config": args.config, "level": cfg["level"],
                        "frames_per_gpu": F, "parallelism": f"frame ranges x{world}",
-                       "contexts": len(ans)},
+                       "contexts": len(ans),
+                       "prewarm": f"{prewarm_steps} untimed steps ({args.prewarm_ms:.0f} ms) before the warm-up"},
+            "sustained": sustained,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
             "kernels": kernels,
             "mfma_autocorr_experiment": mfma_exp,
             "device_verify": verify,
-            "compression_ratio": round(compressed_bytes / (F * BLOCK * CHANNELS * 3), 4),
+            "compression_ratio": round(compressed_bytes / (F * BLOCK * C * ((BPS + 7) // 8)), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
-            "parity_checked_frames": check,
+            "parity": {"frames_byte_identical_to_oracle_per_rank": check, "distinct_frames_in_batch": check,
+                       "frames_round_tripped_on_device_per_rank": F, "ranks_checked": world},
             "analysis_stats": analysis_stats,
             "shard_counters": counters,
         }
