@@ -139,6 +139,17 @@ def _load():
     L.flacenc_pack_frames.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, ip, C.c_uint32,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.flacgpu_host_alloc.argtypes = [C.c_size_t]
+    L.flacgpu_host_alloc.restype = vp
+    L.flacgpu_host_free.argtypes = [vp]
+    L.flacgpu_host_free.restype = None
+    L.flacgpu_current_device.argtypes = []
+    L.flacgpu_packed_input_supported.argtypes = [vp, C.c_uint32]
+    L.flacgpu_encode_packed_async.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                              C.c_uint32]
+    L.flacgpu_frames_ready.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+    L.flacgpu_fetch_frames_async.argtypes = [vp, C.c_void_p, C.c_size_t]
+    L.flacgpu_wait.argtypes = [vp]
     L.flacgpu_verify_device.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(VerifyResult),
                                         C.POINTER(C.c_float)]
     L.flacgpu_fetch_decoded.argtypes = [vp, ip]

@@ -38,6 +38,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -86,6 +87,10 @@ struct flacgpu_ctx {
     uint32_t window_last_len = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;  // stream the last analysis / assembly was submitted to
+    // asynchronous host path (flacgpu_encode_packed_async ...)
+    uint64_t *h_off = nullptr;          // pinned: byte offsets of the frames of the batch in flight
+    hipEvent_t ev_sizes = nullptr, ev_bytes = nullptr, ev_null = nullptr;
+    bool sizes_pending = false, bytes_pending = false;
     // last call
     uint32_t last_frames = 0, last_len = 0;
     bool timing = false;
@@ -94,6 +99,23 @@ struct flacgpu_ctx {
     bool ev_used[FLACGPU_N_KERNELS];
     float last_ms[FLACGPU_N_KERNELS];
 };
+
+// Every entry point runs with the context's device current and restores the caller's device on
+// the way out (a context may be created on one thread and used from another, whose current
+// device is a different GPU).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define CTX_GUARD(c) DeviceGuard device_guard_((c)->device)
 
 // Waits for the work this context submitted last (never for other contexts: no device-wide sync).
 static hipStream_t ctx_stream(flacgpu_ctx *c) { return c->last_stream ? c->last_stream : c->own_stream; }
@@ -206,6 +228,36 @@ bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_fram
     return false;
 }
 
+// K0 for stream-width little-endian input (k_deinterleave_packed); false: no instantiation / layout
+// the kernel cannot take (the caller widens on the host instead)
+bool packed_k0_supported(uint32_t block_size, uint32_t channels, uint32_t bytes) {
+    return bytes >= 1 && bytes <= 3 && block_size % 4 == 0 && ((size_t)block_size * channels * bytes) % 16 == 0;
+}
+template <int C>
+void launch_k0_packed_c(flacgpu_ctx *c, uint32_t bytes, const dim3 &grid, uint32_t n_frames, uint32_t last_len,
+                        uint32_t f0, hipStream_t st) {
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(c->d_in);
+    const uint32_t B = c->opts.block_size;
+    switch (bytes) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 1>), grid, dim3(WG), 0, st, in, c->d_planar, B,
+                               c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 2>), grid, dim3(WG), 0, st, in, c->d_planar, B,
+                               c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 3>), grid, dim3(WG), 0, st, in, c->d_planar, B,
+                                c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+    }
+}
+void launch_k0_packed(flacgpu_ctx *c, uint32_t bytes, uint32_t n_frames, uint32_t last_len, hipStream_t st) {
+    const uint32_t B = c->opts.block_size;
+    const dim3 grid(std::max<uint32_t>(1u, (B / 4 + WG - 1) / WG), n_frames);   // 4 PCM frames per lane
+    switch (c->channels) {
+#define X(C) case C: launch_k0_packed_c<C>(c, bytes, grid, n_frames, last_len, 0, st); break;
+        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+    default: break;
+    }
+}
+
 const char *const kKernelNames[FLACGPU_N_KERNELS] = {
     "k_deinterleave", "k_stereo_stats", "k_fixed", "k_autocorr", "k_lpc",
     "k_fir",          "k_decide",       "k_emit",  "k_layout",   "k_pack",
@@ -230,6 +282,25 @@ const char *flacgpu_kernel_name(int i) {
     return (i >= 0 && i < FLACGPU_N_KERNELS) ? kKernelNames[i] : "";
 }
 
+// dynamic-LDS opt-ins are per kernel and per device: set once per device, to the largest block the
+// LDS-resident generic kernels accept (k_fixed / k_fir: 2 * block_size * 4 bytes and change)
+static int set_kernel_attributes_once(int device) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64 || done[device]) return FLACGPU_OK;
+    const size_t B = FLACGPU_MAX_BLOCK_SIZE;
+    const int dyn = (int)((2 * B + B / 16 + 16) * sizeof(int32_t));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
+    HIP_TRY(pack_set_attributes(pack_lds_bytes((uint32_t)B)));
+    done[device] = true;
+    return FLACGPU_OK;
+}
+
+static int create_impl(flacgpu_ctx *c, const flacgpu_options *o);
+
 int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, int device,
                    uint32_t max_frames, flacgpu_ctx **out) {
     if (!o || !out) return FLACGPU_ERR_INVALID_ARG;
@@ -250,14 +321,32 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
         g_last_error = "no HIP device";
         return FLACGPU_ERR_NO_DEVICE;
     }
-    if (device >= 0) HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) {
+        g_last_error = "no such HIP device";
+        return FLACGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0) HIP_TRY(hipGetDevice(&device));   // -1: the caller's current device
     flacgpu_ctx *c = new flacgpu_ctx();
     c->opts = *o;
     c->bps = bps;
     c->channels = channels;
     c->max_frames = max_frames;
     c->device = device;
+    int rc;
+    {
+        CTX_GUARD(c);   // the caller's current device is left as it was
+        rc = create_impl(c, o);
+    }
+    if (rc != FLACGPU_OK) {
+        flacgpu_destroy(c);   // frees whatever was allocated before the failure
+        return rc;
+    }
+    *out = c;
+    return FLACGPU_OK;
+}
+
+static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
+    const uint32_t max_frames = c->max_frames, channels = c->channels, bps = c->bps;
     c->ldb = (o->block_size + 3u) & ~3u;
     c->stereo4 = (channels == 2 && bps < 32) ? 1u : 0u;  // side needs bps+1 <= 32 (encode.rs:2715)
     c->ncand = c->stereo4 ? 4u : channels;
@@ -298,20 +387,25 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     HIP_TRY(hipMemcpyAsync(c->d_log2_thr, thr, sizeof thr, hipMemcpyHostToDevice, c->own_stream));
     HIP_TRY(hipStreamSynchronize(c->own_stream));
     if (int rc = upload_window(c, o->block_size, c->d_window_full, c->own_stream)) return rc;
-    // k_fixed / k_fir use 2 * block_size * 4 bytes of dynamic LDS (up to 128 KiB of the 160)
-    const int dyn = (int)((2 * B + B / 16 + 16) * sizeof(int32_t));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
-    HIP_TRY(pack_set_attributes(pack_lds_bytes((uint32_t)B)));
+    if (int rc = set_kernel_attributes_once(c->device)) return rc;
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_sizes, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_bytes, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&c->h_off, sizeof(uint64_t) * (F + 1), hipHostMallocDefault));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
-    *out = c;
     return FLACGPU_OK;
 }
 
 void flacgpu_destroy(flacgpu_ctx *c) {
     if (!c) return;
+    CTX_GUARD(c);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->h_off) (void)hipHostFree(c->h_off);
+    if (c->ev_sizes) (void)hipEventDestroy(c->ev_sizes);
+    if (c->ev_bytes) (void)hipEventDestroy(c->ev_bytes);
+    if (c->ev_null) (void)hipEventDestroy(c->ev_null);
     (void)hipFree(c->d_in); (void)hipFree(c->d_planar); (void)hipFree(c->d_resid); (void)hipFree(c->d_window_full);
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
@@ -369,8 +463,38 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
 
 }
 
+// stream == NULL: the context's own (non-blocking) stream, ordered AFTER whatever the caller has
+// already submitted to the legacy default stream (producers of d_pcm there are safe); results are
+// ordered on the context's stream, which every fetch / wait entry point synchronises.
+static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
+    if (stream) {
+        *out = (hipStream_t)stream;
+        return FLACGPU_OK;
+    }
+    HIP_TRY(hipEventRecord(c->ev_null, nullptr));
+    HIP_TRY(hipStreamWaitEvent(c->own_stream, c->ev_null, 0));
+    *out = c->own_stream;
+    return FLACGPU_OK;
+}
+
+// packed_bytes != 0: the PCM sits in c->d_in as interleaved little-endian samples of that many bytes
+static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                        uint32_t last_len, hipStream_t st, uint32_t packed_bytes);
+
 int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
                            uint32_t last_len, void *stream) {
+    if (!c || !d_pcm) {
+        g_last_error = "invalid analyze arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    hipStream_t st;
+    if (int rc = resolve_stream(c, stream, &st)) return rc;
+    return analyze_impl(c, d_pcm, layout, n_frames, last_len, st, 0);
+}
+
+static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                        uint32_t last_len, hipStream_t st, uint32_t packed_bytes) {
     if (!c || !d_pcm || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
         last_len > c->opts.block_size || (layout != 0 && layout != 1)) {
         g_last_error = "invalid analyze arguments";
@@ -385,7 +509,6 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
             return FLACGPU_ERR_UNSUPPORTED;
         }
     }
-    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
     if (last_len != B && last_len != c->window_last_len) {
         if (int rc = upload_window(c, last_len, c->d_window_last, st)) return rc;
         c->window_last_len = last_len;
@@ -412,10 +535,13 @@ int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uin
     const uint32_t ncb = n_frames * c->ncand;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)ncb), st));  // + d_orbits
     // K0 (+ OR of every candidate's samples -> wasted bits)
-    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
+    const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
     begin(0);
     bool have_orbits = false;
-    if (planar_direct) {
+    if (packed_bytes) {
+        launch_k0_packed(c, packed_bytes, n_frames, last_len, st);
+        have_orbits = true;
+    } else if (planar_direct) {
         p.planar = d_pcm;  // [frame][ch][B] with ldb == B
     } else {
         have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, 0, n_frames, st);
@@ -514,6 +640,7 @@ static int ensure_residual_rows(flacgpu_ctx *c) {
 int flacgpu_fetch(flacgpu_ctx *c, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subs,
                   int32_t *residuals) {
     if (!c || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
     const size_t F = c->last_frames;
     hipStream_t st = c->own_stream;
     if (int rc = ctx_sync(c)) return rc;
@@ -538,15 +665,20 @@ int flacgpu_analyze(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32_t n_f
         g_last_error = "invalid analyze arguments";
         return FLACGPU_ERR_INVALID_ARG;
     }
+    CTX_GUARD(c);
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
     HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, c->own_stream));
     // planar host input with a short last frame is laid out [frame][ch][len]; handled by K0
-    int rc = flacgpu_analyze_device(c, c->d_in, layout, n_frames, last_len, c->own_stream);
+    int rc = analyze_impl(c, c->d_in, layout, n_frames, last_len, c->own_stream, 0);
     if (rc) return rc;
     return flacgpu_fetch(c, plans, subs, residuals);
 }
 
+
+// after_layout: an event recorded right behind k_layout (the frame sizes are known from there on)
+static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate, hipStream_t st,
+                     hipEvent_t after_layout);
 
 int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate,
                         void *stream) {
@@ -554,7 +686,14 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
         g_last_error = "flacgpu_pack_device: no analysed batch";
         return FLACGPU_ERR_INVALID_ARG;
     }
-    hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+    CTX_GUARD(c);
+    hipStream_t st;
+    if (int rc = resolve_stream(c, stream, &st)) return rc;
+    return pack_impl(c, first_frame_number, sample_rate, st, nullptr);
+}
+
+static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate, hipStream_t st,
+                     hipEvent_t after_layout) {
     const Params &p = c->last_params;
     PackParams q;
     q.first_frame_number = first_frame_number;
@@ -565,6 +704,7 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
     if (c->timing) (void)hipEventRecord(ev[0], st);
     launch_layout(p, q, st);
+    if (after_layout) HIP_TRY(hipEventRecord(after_layout, st));
     // frames of a wave block length are assembled whole in LDS by k_frame64 (residuals recomputed
     // from the PCM, CRC-16 from LDS, one write of the finished bytes); any other frame goes
     // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
@@ -644,6 +784,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
                           uint32_t last_len, uint64_t first_frame_number, uint32_t sample_rate,
                           void *stream) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
     const uint32_t B = c->opts.block_size;
     const uint32_t fbw = frame_fb_words(c->channels, c->bps, B);
     const bool eligible =
@@ -654,11 +795,16 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         (size_t)fbw * sizeof(int32_t) <= 150 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
         !getenv("FLACGPU_NO_W64") && !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64") &&
         c->two_ranges;
+    hipStream_t st0;
+    if (int rc = resolve_stream(c, stream, &st0)) return rc;
     if (!eligible) {
-        if (int rc = flacgpu_analyze_device(c, d_pcm, layout, n_frames, last_len, stream)) return rc;
-        return flacgpu_pack_device(c, first_frame_number, sample_rate, stream);
+        if (!d_pcm) {
+            g_last_error = "invalid encode arguments";
+            return FLACGPU_ERR_INVALID_ARG;
+        }
+        if (int rc = analyze_impl(c, d_pcm, layout, n_frames, last_len, st0, 0)) return rc;
+        return pack_impl(c, first_frame_number, sample_rate, st0, nullptr);
     }
-    hipStream_t st0 = stream ? (hipStream_t)stream : c->own_stream;
     hipStream_t st1 = c->aux_stream;
     Params p;
     fill_params(c, n_frames, last_len, p);
@@ -719,6 +865,7 @@ int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *off
         g_last_error = "flacgpu_fetch_frames: nothing packed";
         return FLACGPU_ERR_INVALID_ARG;
     }
+    CTX_GUARD(c);
     const size_t F = c->last_frames;
     if (int rc = ctx_sync(c)) return rc;
     std::vector<uint64_t> off;
@@ -746,6 +893,7 @@ int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32
         g_last_error = "invalid encode arguments";
         return FLACGPU_ERR_INVALID_ARG;
     }
+    CTX_GUARD(c);
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
     HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, c->own_stream));
@@ -755,6 +903,98 @@ int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32
     return flacgpu_fetch_frames(c, out, cap, offsets, total);
 }
 
+// ---- asynchronous host path ------------------------------------------------------------------
+void *flacgpu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        g_last_error = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+void flacgpu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+int flacgpu_current_device(void) {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_sample) {
+    return c && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample) ? 1 : 0;
+}
+
+int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                uint32_t n_frames, uint32_t last_len, uint64_t first_frame_number,
+                                uint32_t sample_rate) {
+    if (!c || !pcm_le || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size ||
+        !(bytes_per_sample == 4 || (bytes_per_sample == (c->bps + 7) / 8 &&
+                                    packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample)))) {
+        g_last_error = "flacgpu_encode_packed_async: invalid arguments / unsupported sample width for this stream shape";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    hipStream_t st = c->own_stream;
+    const size_t B = c->opts.block_size, C = c->channels;
+    const size_t bytes = ((size_t)(n_frames - 1) * B + last_len) * C * bytes_per_sample;
+    HIP_TRY(hipMemcpyAsync(c->d_in, pcm_le, bytes, hipMemcpyHostToDevice, st));
+    if (int rc = analyze_impl(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, st,
+                              bytes_per_sample == 4 ? 0 : bytes_per_sample))
+        return rc;
+    // the frame sizes leave the device as soon as k_layout has run (second stream), so that the host
+    // can size the copy of the bytes while k_frame64 is still assembling them
+    if (int rc = pack_impl(c, first_frame_number, sample_rate, st, c->ev_layout)) return rc;
+    HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_layout, 0));
+    HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
+                           hipMemcpyDeviceToHost, c->aux_stream));
+    HIP_TRY(hipEventRecord(c->ev_sizes, c->aux_stream));
+    c->sizes_pending = true;
+    c->bytes_pending = false;
+    return FLACGPU_OK;
+}
+
+int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *total) {
+    if (!c || !c->sizes_pending) {
+        g_last_error = "flacgpu_frames_ready: no asynchronous batch in flight";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    HIP_TRY(hipEventSynchronize(c->ev_sizes));
+    if (offsets) *offsets = c->h_off;
+    if (total) *total = c->h_off[c->last_frames];
+    return FLACGPU_OK;
+}
+
+int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
+    if (!c || !c->sizes_pending || !out) {
+        g_last_error = "flacgpu_fetch_frames_async: no asynchronous batch in flight";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    HIP_TRY(hipEventSynchronize(c->ev_sizes));
+    const uint64_t bytes = c->h_off[c->last_frames];
+    if (cap < bytes) {
+        g_last_error = "output buffer too small";
+        return FLACGPU_ERR_BUFFER_TOO_SMALL;
+    }
+    HIP_TRY(hipMemcpyAsync(out, c->d_packed, bytes, hipMemcpyDeviceToHost, c->own_stream));
+    HIP_TRY(hipEventRecord(c->ev_bytes, c->own_stream));
+    c->bytes_pending = true;
+    return FLACGPU_OK;
+}
+
+int flacgpu_wait(flacgpu_ctx *c) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
+    if (c->bytes_pending) {
+        HIP_TRY(hipEventSynchronize(c->ev_bytes));
+        c->bytes_pending = false;
+        c->sizes_pending = false;
+        return FLACGPU_OK;
+    }
+    return ctx_sync(c);
+}
+
 int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t *compared,
                                      uint32_t *params_differ, double *max_rel_err) {
     if (!c || c->last_frames == 0 || c->opts.max_lpc_order == 0 || c->opts.max_lpc_order > 16 ||
@@ -762,6 +1002,7 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
         g_last_error = "mfma experiment: needs an analysed batch of full blocks with 1 <= max_lpc_order <= 16";
         return FLACGPU_ERR_INVALID_ARG;
     }
+    CTX_GUARD(c);
     hipStream_t st = c->own_stream;
     Params p = c->last_params;
     const size_t nc = (size_t)p.n_frames * p.ncand;
@@ -813,6 +1054,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
         g_last_error = "flacgpu_verify_device: nothing packed";
         return FLACGPU_ERR_INVALID_ARG;
     }
+    CTX_GUARD(c);
     hipStream_t st = c->own_stream;
     Params p = c->last_params;
     const size_t F = c->max_frames, C = c->channels;
@@ -871,6 +1113,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
 
 int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
     if (!c || !c->d_decoded || !interleaved || c->last_frames == 0) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
     const size_t F = c->last_frames, C = c->channels, B = c->opts.block_size, ldb = c->ldb;
     std::vector<int32_t> planar(F * C * ldb);
     if (int rc = ctx_sync(c)) return rc;
@@ -886,6 +1129,7 @@ int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
 
 int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     if (!c || !out) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
     uint32_t s[4];
     if (int rc = ctx_sync(c)) return rc;
     if (int rc = copy_sync(c, s, c->d_stats, sizeof s, hipMemcpyDeviceToHost)) return rc;
@@ -898,6 +1142,7 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
 
 void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     if (!c) return nullptr;
+    CTX_GUARD(c);
     switch (which) {
     case 0: return c->d_fplan;
     case 1: return c->d_out;

@@ -5,6 +5,8 @@
 // metadata.  C ABI: include/flacenc_stream.h.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <future>
 #include <cstdio>
 #include <cstring>
@@ -245,48 +247,160 @@ int pack_batch(uint32_t sample_rate, uint32_t bps, uint32_t channels, uint64_t f
 // =====================================================================================
 // Encoder<W>, encode.rs:1853-2110
 // =====================================================================================
-// Idle analysis contexts, keyed by everything flacgpu_create depends on.  Creating a context costs
-// a dozen hipMalloc calls and destroying it as many hipFree calls, which synchronise the whole
-// device: with many short streams (a music library) they dominate.  Writers return their context
-// here; at most kPoolCap idle contexts are kept (the rest are destroyed), the process exit reclaims.
+// Idle analysis lanes, keyed by everything flacgpu_create depends on.  A lane is what one batch in
+// flight needs: an analysis context (a dozen hipMalloc calls to create, as many hipFree calls to
+// destroy, each a device-wide synchronisation: with many short streams -- a music library -- they
+// dominate) and two pinned staging buffers (PCM at stream width in, frame bytes out; pinning memory
+// is slower still).  Writers return their lanes here; at most kPoolCap idle lanes are kept (the rest
+// are destroyed), the process exit reclaims.
 struct CtxKey {
     flacgpu_options g;
     uint32_t bps, channels, batch;
-    int device;
+    int device;   // resolved ordinal, never -1: a pooled context must not change GPUs
     bool operator==(const CtxKey &o) const {
         return std::memcmp(&g, &o.g, sizeof g) == 0 && bps == o.bps && channels == o.channels &&
                batch == o.batch && device == o.device;
     }
 };
-struct CtxPool {
-    static constexpr size_t kPoolCap = 64;
+struct Lane {
+    flacgpu_ctx *gpu = nullptr;
+    uint8_t *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    int reserve_in(size_t n) {
+        if (n <= pin_in_cap) return 0;
+        flacgpu_host_free(pin_in);
+        pin_in = static_cast<uint8_t *>(flacgpu_host_alloc(n));
+        pin_in_cap = pin_in ? n : 0;
+        return pin_in ? 0 : FLACENC_ERR_GPU;
+    }
+    int reserve_out(size_t n) {
+        if (n <= pin_out_cap) return 0;
+        flacgpu_host_free(pin_out);
+        n += n / 8;   // a little head room: the next batch of the stream is about as large
+        pin_out = static_cast<uint8_t *>(flacgpu_host_alloc(n));
+        pin_out_cap = pin_out ? n : 0;
+        return pin_out ? 0 : FLACENC_ERR_GPU;
+    }
+    void destroy() {
+        if (gpu) flacgpu_destroy(gpu);
+        flacgpu_host_free(pin_in);
+        flacgpu_host_free(pin_out);
+        delete this;
+    }
+};
+struct LanePool {
+    static constexpr size_t kPoolCap = 192;
     std::mutex mu;
-    std::vector<std::pair<CtxKey, flacgpu_ctx *>> idle;
-    flacgpu_ctx *take(const CtxKey &k) {
+    std::vector<std::pair<CtxKey, Lane *>> idle;
+    Lane *take(const CtxKey &k) {
         std::lock_guard<std::mutex> lock(mu);
         for (size_t i = 0; i < idle.size(); i++) {
             if (idle[i].first == k) {
-                flacgpu_ctx *c = idle[i].second;
+                Lane *l = idle[i].second;
                 idle.erase(idle.begin() + static_cast<ptrdiff_t>(i));
-                return c;
+                return l;
             }
         }
         return nullptr;
     }
-    void give(const CtxKey &k, flacgpu_ctx *c) {
+    void give(const CtxKey &k, Lane *l) {
         {
             std::lock_guard<std::mutex> lock(mu);
             if (idle.size() < kPoolCap) {
-                idle.emplace_back(k, c);
+                idle.emplace_back(k, l);
                 return;
             }
         }
-        flacgpu_destroy(c);
+        l->destroy();
     }
 };
-CtxPool &ctx_pool() {
-    static CtxPool *p = new CtxPool();  // intentionally leaked: no HIP calls during static destruction
+LanePool &lane_pool() {
+    static LanePool *p = new LanePool();  // intentionally leaked: no HIP calls during static destruction
     return *p;
+}
+
+// The stream MD5 is one serial chain over the PCM bytes (encode.rs:571, 1292-1318): it runs on a
+// thread of its own, fed in stream order with the very buffers that are being uploaded.
+struct Md5Worker {
+    Md5 *md5 = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<const uint8_t *, size_t>> q;
+    uint64_t pushed = 0, done = 0;
+    bool stop = false;
+    double busy_ms = 0;
+    uint64_t push(const uint8_t *p, size_t n) {
+        std::unique_lock<std::mutex> lock(mu);
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        q.emplace_back(p, n);
+        const uint64_t ticket = ++pushed;
+        cv.notify_all();
+        return ticket;
+    }
+    void wait(uint64_t ticket) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return done >= ticket; });
+    }
+    void run() {
+        std::unique_lock<std::mutex> lock(mu);
+        for (;;) {
+            cv.wait(lock, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;
+            auto job = q.front();
+            q.pop_front();
+            lock.unlock();
+            const double t0 = now_ms();
+            md5->update(job.first, job.second);
+            const double dt = now_ms() - t0;
+            lock.lock();
+            busy_ms += dt;
+            done++;
+            cv.notify_all();
+        }
+    }
+    ~Md5Worker() {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
+// interleaved int32 samples -> little-endian samples of `width` bytes (update_md5's byte string,
+// encode.rs:1292-1318; byteorder.rs:60-72)
+void pack_le(const int32_t *s, size_t count, unsigned width, uint8_t *d) {
+    switch (width) {
+    case 1:
+        for (size_t i = 0; i < count; i++) d[i] = static_cast<uint8_t>(s[i]);
+        break;
+    case 2: {
+        uint16_t *o = reinterpret_cast<uint16_t *>(d);
+        for (size_t i = 0; i < count; i++) o[i] = static_cast<uint16_t>(s[i]);   // little-endian hosts only
+        break;
+    }
+    case 3: {
+        size_t i = 0;
+        uint32_t *o = reinterpret_cast<uint32_t *>(d);
+        for (; i + 4 <= count; i += 4, o += 3) {   // four samples -> three dwords
+            const uint32_t a = static_cast<uint32_t>(s[i]), b = static_cast<uint32_t>(s[i + 1]),
+                           c = static_cast<uint32_t>(s[i + 2]), e = static_cast<uint32_t>(s[i + 3]);
+            o[0] = (a & 0xFFFFFFu) | (b << 24);
+            o[1] = ((b >> 8) & 0xFFFFu) | (c << 16);
+            o[2] = ((c >> 16) & 0xFFu) | (e << 8);
+        }
+        for (; i < count; i++) {
+            const uint32_t v = static_cast<uint32_t>(s[i]);
+            d[3 * i] = static_cast<uint8_t>(v);
+            d[3 * i + 1] = static_cast<uint8_t>(v >> 8);
+            d[3 * i + 2] = static_cast<uint8_t>(v >> 16);
+        }
+        break;
+    }
+    default: std::memcpy(d, s, count * 4); break;
+    }
 }
 
 struct flacenc_writer {
@@ -297,10 +411,24 @@ struct flacenc_writer {
     MetaLayout meta;
     size_t metadata_len = 0;
     uint64_t frame_number = 0, samples_written = 0, byte_count = 0;  // Counter::count
+    uint64_t samples_submitted = 0;   // samples_written + the batches still in flight
     std::vector<SeekPoint> seekpoints;
     Md5 md5;
     bool finalized = false;
-    flacgpu_ctx *gpu = nullptr;
+    flacgpu_ctx *gpu = nullptr;   // = lanes[0]->gpu (the synchronous paths use this one)
+    // batches in flight (device-side frame assembly): lanes taken from the pool, the oldest retired first
+    struct InFlight {
+        Lane *lane;
+        uint32_t n_frames, last_len;
+        uint64_t md5_ticket;
+    };
+    std::vector<Lane *> lanes;
+    std::deque<InFlight> inflight;
+    size_t next_lane = 0;
+    unsigned depth = 2;           // batches in flight
+    unsigned upload_width = 4;    // bytes per sample across PCIe
+    Md5Worker md5_worker;
+    int failed = 0;               // first error of an asynchronous batch
     uint32_t batch_frames = 1024;
     unsigned pack_threads = 1;
     // backlog of interleaved samples not yet cut into blocks (FlacSampleWriter::sample_buf)
@@ -319,7 +447,23 @@ struct flacenc_writer {
 
     CtxKey gpu_key{};
     ~flacenc_writer() {
-        if (gpu) ctx_pool().give(gpu_key, gpu);
+        for (auto &f : inflight) (void)flacgpu_wait(f.lane->gpu);   // nothing may still write into a pooled lane
+        for (Lane *l : lanes) lane_pool().give(gpu_key, l);
+    }
+
+    // one more lane (context + staging) for this stream shape, from the pool or new
+    int add_lane() {
+        Lane *l = lane_pool().take(gpu_key);
+        if (!l) {
+            l = new Lane();
+            int rc = flacgpu_create(&gpu_key.g, gpu_key.bps, gpu_key.channels, gpu_key.device, batch_frames, &l->gpu);
+            if (rc) {
+                delete l;
+                return map_gpu_error(rc);
+            }
+        }
+        lanes.push_back(l);
+        return 0;
     }
 
     // Encoder::new, encode.rs:1882-1980
@@ -386,12 +530,12 @@ struct flacenc_writer {
         gpu_key.bps = bps;
         gpu_key.channels = channels;
         gpu_key.batch = batch_frames;
-        gpu_key.device = o.device;
-        gpu = ctx_pool().take(gpu_key);
-        if (!gpu) {
-            int rc = flacgpu_create(&g, bps, channels, o.device, batch_frames, &gpu);
-            if (rc) return map_gpu_error(rc);
-        }
+        gpu_key.device = o.device >= 0 ? o.device : flacgpu_current_device();
+        if (int rc = add_lane()) return rc;
+        gpu = lanes[0]->gpu;
+        depth = o.pipeline_depth ? std::min<uint32_t>(o.pipeline_depth, 4u) : 2u;
+        upload_width = flacgpu_packed_input_supported(gpu, bytes_per_sample) ? bytes_per_sample : 4u;
+        md5_worker.md5 = &md5;
         return 0;
     }
 
@@ -509,6 +653,117 @@ struct flacenc_writer {
         return deferred;
     }
 
+    // ---- device-side frame assembly, pipelined: Encoder::encode for a run of blocks (encode.rs:
+    // 1997-2022) is split into SUBMIT (stage the PCM at stream width in pinned memory, queue upload +
+    // kernels, hand the same bytes to the MD5 thread) and RETIRE (sizes, copy of the bytes, seek
+    // points / STREAMINFO bookkeeping and the sink write, encode.rs:1999-2003, 2414-2436), with up
+    // to `depth` batches in flight on their own contexts and streams.
+    int submit_blocks(const int32_t *interleaved, uint32_t n_frames, uint32_t last_len) {
+        if (failed) return failed;
+        const uint32_t B = o.block_size, C = si.channels;
+        // ExcessiveTotalSamples is raised BEFORE the offending frame is encoded (:2006-2011)
+        uint32_t usable = n_frames;
+        int deferred = 0;
+        if (si.total_samples) {
+            uint64_t w = samples_submitted;
+            for (uint32_t f = 0; f < n_frames; f++) {
+                w += (f + 1 == n_frames) ? last_len : B;
+                if (w > si.total_samples) {
+                    usable = f;
+                    deferred = FLACENC_ERR_EXCESSIVE_TOTAL_SAMPLES;
+                    break;
+                }
+            }
+        }
+        const size_t all_samples = (static_cast<size_t>(n_frames - 1) * B + last_len) * C;
+        if (usable) {
+            const uint32_t ll = (usable == n_frames) ? last_len : B;
+            if (frame_number + usable - 1 > kMaxFrameNumber) return FLACENC_ERR_EXCESSIVE_FRAME_NUMBER;
+            while (inflight.size() >= depth)
+                if (int rc = retire_oldest()) return rc;
+            // lanes are used round-robin and retired in order: lane (n mod depth) is free again
+            const size_t idx = next_lane;
+            next_lane = (next_lane + 1) % depth;
+            while (lanes.size() <= idx)
+                if (int rc = add_lane()) return rc;
+            Lane *lane = lanes[idx];
+            const size_t count = (static_cast<size_t>(usable - 1) * B + ll) * C;
+            const double t0 = now_ms();
+            if (int rc = lane->reserve_in(static_cast<size_t>(batch_frames) * B * C * 4 + 64)) return rc;
+            pack_le(interleaved, count, upload_width, lane->pin_in);
+            stats.pack_ms += now_ms() - t0;
+            // MD5 of the whole call's samples (the frame that trips ExcessiveTotalSamples included:
+            // the reference hashes before it encodes, encode.rs:571-577)
+            uint64_t ticket;
+            if (upload_width == bytes_per_sample && usable == n_frames) {
+                ticket = md5_worker.push(lane->pin_in, count * bytes_per_sample);
+            } else {
+                md5_worker.wait(md5_worker.pushed);   // keep the chain in stream order
+                md5_samples(interleaved, all_samples);
+                ticket = md5_worker.pushed;
+            }
+            const double t1 = now_ms();
+            int rc = flacgpu_encode_packed_async(lane->gpu, lane->pin_in, upload_width, usable, ll, frame_number,
+                                                 si.sample_rate);
+            stats.gpu_ms += now_ms() - t1;
+            if (rc) return map_gpu_error(rc);
+            inflight.push_back({lane, usable, ll, ticket});
+            frame_number += usable;
+            samples_submitted += static_cast<uint64_t>(usable - 1) * B + ll;
+        } else {
+            md5_worker.wait(md5_worker.pushed);
+            md5_samples(interleaved, all_samples);
+        }
+        if (deferred) {
+            if (int rc = retire_all()) return rc;
+            // the reference pushes the seekpoint and bumps samples_written before failing
+            seekpoints.push_back({samples_written, byte_count, static_cast<uint16_t>(B), true});
+            samples_written += (usable + 1 == n_frames) ? last_len : B;
+            samples_submitted = samples_written;
+        }
+        return deferred;
+    }
+
+    int retire_oldest() {
+        InFlight f = inflight.front();
+        inflight.pop_front();
+        const uint32_t B = o.block_size;
+        const double t0 = now_ms();
+        const uint64_t *off = nullptr;
+        uint64_t total = 0;
+        int rc = flacgpu_frames_ready(f.lane->gpu, &off, &total);
+        if (!rc) rc = f.lane->reserve_out(total + 64) ? FLACGPU_ERR_HIP : 0;
+        if (!rc) rc = flacgpu_fetch_frames_async(f.lane->gpu, f.lane->pin_out, f.lane->pin_out_cap);
+        if (!rc) rc = flacgpu_wait(f.lane->gpu);
+        stats.gpu_ms += now_ms() - t0;
+        md5_worker.wait(f.md5_ticket);   // the staging buffer is free again only after its hash
+        if (rc) {
+            failed = map_gpu_error(rc);
+            return failed;
+        }
+        for (uint32_t k = 0; k < f.n_frames; k++) {
+            const uint32_t n = (k + 1 == f.n_frames) ? f.last_len : B;
+            seekpoints.push_back({samples_written, byte_count + off[k], static_cast<uint16_t>(n), true});
+            samples_written += n;
+            const uint32_t size = static_cast<uint32_t>(off[k + 1] - off[k]);
+            if (size != 0 && size < kMaxFrameSize) {  // :2414-2436
+                si.min_frame = si.min_frame ? std::min(si.min_frame, size) : size;
+                si.max_frame = std::max(si.max_frame, size);
+            }
+        }
+        byte_count += total;
+        if (int e = sink.write(f.lane->pin_out, total)) {
+            failed = e;
+            return e;
+        }
+        return 0;
+    }
+    int retire_all() {
+        while (!inflight.empty())
+            if (int rc = retire_oldest()) return rc;
+        return failed;
+    }
+
     // Cut whole blocks out of `data` (count samples), batch by batch; returns the samples consumed
     // through *consumed_out: whole batches, or every whole block at the final flush.
     int process(const int32_t *data, size_t count, bool final_flush, size_t *consumed_out) {
@@ -517,6 +772,16 @@ struct flacenc_writer {
         int rc = 0;
         size_t whole_all = count / frame_samples;
         if (!final_flush) whole_all -= whole_all % batch_frames;
+        if (!o.host_pack) {   // batches in flight; the MD5 follows the staging buffers
+            while (rc == 0 && consumed < whole_all * frame_samples) {
+                const size_t whole = whole_all - consumed / frame_samples;
+                const uint32_t take = static_cast<uint32_t>(std::min<size_t>(whole, batch_frames));
+                rc = submit_blocks(data + consumed, take, o.block_size);
+                consumed += take * frame_samples;
+            }
+            *consumed_out = consumed;
+            return rc;
+        }
         // The stream MD5 is one serial chain over the PCM (encode.rs:571): it runs on its own
         // host thread over the samples of this call while the GPU batches are in flight
         std::future<void> md5_job;
@@ -588,11 +853,18 @@ struct flacenc_writer {
                 g_err = "final partial block holds less than one PCM frame (the reference panics)";
                 return FLACENC_ERR_UNSUPPORTED;
             }
-            md5_samples(backlog.data(), usable);
-            rc = encode_blocks(backlog.data(), 1, static_cast<uint32_t>(usable / si.channels));
+            if (o.host_pack) {
+                md5_samples(backlog.data(), usable);
+                rc = encode_blocks(backlog.data(), 1, static_cast<uint32_t>(usable / si.channels));
+            } else {
+                rc = submit_blocks(backlog.data(), 1, static_cast<uint32_t>(usable / si.channels));
+            }
             backlog.clear();
             if (rc) return rc;
         }
+        if (int e = retire_all()) return e;
+        md5_worker.wait(md5_worker.pushed);
+        stats.md5_ms += md5_worker.busy_ms;
         return finalize_encoder();
     }
 

@@ -92,7 +92,7 @@ class _COptions(C.Structure):
         ("vendor_string", C.c_char_p),
         ("comment_fields", C.POINTER(C.c_char_p)),
         ("n_comment_fields", C.c_uint32),
-        ("reserved2", C.c_uint32),
+        ("pipeline_depth", C.c_uint32),
     ]
 
 
@@ -308,6 +308,11 @@ class Options:
 
     def pack_threads(self, n):
         self._c.pack_threads = n
+        return self
+
+    def pipeline_depth(self, n):
+        """Batches in flight per writer (each on its own context / HIP stream / pinned staging)."""
+        self._c.pipeline_depth = n
         return self
 
     def host_pack(self, on=True):

@@ -135,6 +135,51 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_encode_frames")
         return buf[: total.value].tobytes(), list(off)
 
+    def encode_packed(self, pcm_le, bytes_per_sample, n_frames, last_frame_len, first_frame_number,
+                      sample_rate, pinned=True):
+        """The asynchronous host path in one go (flacgpu_encode_packed_async -> frames_ready ->
+        fetch_frames_async -> wait): pcm_le = interleaved little-endian samples of bytes_per_sample
+        bytes (uint8 array).  Returns (bytes, offsets)."""
+        L = _lib.lib()
+        src = np.ascontiguousarray(pcm_le, dtype=np.uint8)
+        hin = hout = None
+        try:
+            if pinned:
+                hin = L.flacgpu_host_alloc(src.size + 64)
+                C.memmove(hin, src.ctypes.data, src.size)
+            rc = L.flacgpu_encode_packed_async(self._h, hin if pinned else src.ctypes.data, bytes_per_sample,
+                                               n_frames, last_frame_len, first_frame_number, sample_rate)
+            if rc:
+                raise GpuError(rc, "flacgpu_encode_packed_async")
+            offp = C.POINTER(C.c_uint64)()
+            total = C.c_uint64(0)
+            rc = L.flacgpu_frames_ready(self._h, C.byref(offp), C.byref(total))
+            if rc:
+                raise GpuError(rc, "flacgpu_frames_ready")
+            off = [offp[i] for i in range(n_frames + 1)]
+            if pinned:
+                hout = L.flacgpu_host_alloc(total.value + 64)
+                dst = hout
+            else:
+                buf = np.empty(total.value + 64, dtype=np.uint8)
+                dst = buf.ctypes.data
+            rc = L.flacgpu_fetch_frames_async(self._h, dst, total.value + 64)
+            if rc:
+                raise GpuError(rc, "flacgpu_fetch_frames_async")
+            rc = L.flacgpu_wait(self._h)
+            if rc:
+                raise GpuError(rc, "flacgpu_wait")
+            data = C.string_at(dst, total.value)
+            return data, off
+        finally:
+            if hin:
+                L.flacgpu_host_free(hin)
+            if hout:
+                L.flacgpu_host_free(hout)
+
+    def packed_input_supported(self, bytes_per_sample):
+        return bool(_lib.lib().flacgpu_packed_input_supported(self._h, bytes_per_sample))
+
     def verify_device(self, sample_rate, first_frame_number=0):
         """Decode the frames packed last on the GPU, check CRC-16 and compare with the analysed
         PCM.  Returns (VerifyResult, kernel_ms)."""

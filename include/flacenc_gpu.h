@@ -149,8 +149,14 @@ int flacgpu_analyze(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n
                     flacgpu_subframe_plan *subframes, int32_t *residuals);
 
 /* Same, PCM already resident in device memory (d_pcm is a device pointer).  Results stay
- * on the device until flacgpu_fetch(); `stream` is a hipStream_t (NULL = default stream).
- * Asynchronous with respect to the host. */
+ * on the device until flacgpu_fetch().  Asynchronous with respect to the host.
+ * `stream` is a hipStream_t.  NULL selects the context's own non-blocking stream, ordered AFTER
+ * everything the caller has already submitted to the legacy default stream (so a d_pcm produced
+ * there is safe to hand over); the results are then ordered on the context's stream, which every
+ * flacgpu_fetch* / flacgpu_get_stats / flacgpu_wait call synchronises.  A caller that chains further
+ * device work on the results passes its own stream instead.
+ * Every entry point makes the context's device current for the duration of the call and restores
+ * the caller's device afterwards. */
 int flacgpu_analyze_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,
                            uint32_t last_frame_len, void *stream);
 /* Copy the results of the last flacgpu_analyze_device to host buffers (any may be NULL). */
@@ -206,6 +212,33 @@ int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint
                           uint32_t last_frame_len, uint64_t first_frame_number,
                           uint32_t sample_rate, uint8_t *out, size_t cap, uint64_t *offsets,
                           uint64_t *total);
+
+/* ---- asynchronous host path: stream-width upload, sizes ahead of the bytes ---------------------
+ * What a streaming front end (FlacSampleWriter / FlacByteWriter, encode.rs:359, 558) needs to keep
+ * several batches in flight: PCM enters as the little-endian `bytes_per_sample = ceil(bps / 8)`-byte
+ * samples that FlacByteWriter::write receives and update_md5 hashes (encode.rs:1292-1318,
+ * byteorder.rs:60-72) -- 2 or 3 bytes per sample across PCIe instead of 4, widened by K0 on the
+ * device --, ideally from pinned memory (flacgpu_host_alloc), so that the copy is asynchronous.
+ *   flacgpu_encode_packed_async  H2D + analysis + frame assembly, all queued; returns at once
+ *   flacgpu_frames_ready         waits for the frame SIZES only (they leave the device right after
+ *                                k_layout, while the bytes are still being assembled); *offsets
+ *                                (n_frames + 1 entries) stays valid until the context's next batch
+ *   flacgpu_fetch_frames_async   queues the copy of exactly those bytes to `out`
+ *   flacgpu_wait                 waits for that copy (or, without one, for the context's stream)
+ * One batch per context at a time; several contexts overlap (H2D of one, kernels of another, D2H of
+ * a third run concurrently on their own streams). */
+void *flacgpu_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc), NULL on failure */
+void flacgpu_host_free(void *p);
+int flacgpu_current_device(void);       /* the caller's current HIP device, -1 without one */
+/* 1 when flacgpu_encode_packed_async takes this sample width for the context's stream shape (a block
+ * must be a whole number of 16-byte groups); otherwise widen to int32 and pass bytes_per_sample 4 */
+int flacgpu_packed_input_supported(const flacgpu_ctx *ctx, uint32_t bytes_per_sample);
+int flacgpu_encode_packed_async(flacgpu_ctx *ctx, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                uint32_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number,
+                                uint32_t sample_rate);
+int flacgpu_frames_ready(flacgpu_ctx *ctx, const uint64_t **offsets, uint64_t *total);
+int flacgpu_fetch_frames_async(flacgpu_ctx *ctx, uint8_t *out, size_t cap);
+int flacgpu_wait(flacgpu_ctx *ctx);
 
 /* ---- device-side decode + verify of the frames packed last ----------
  * The reference's frame decoder (decode.rs:1388-1436 read_frame, 1494-1633 read_subframes,

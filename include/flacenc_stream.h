@@ -89,7 +89,10 @@ typedef struct {
     const char *vendor_string;
     const char *const *comment_fields;
     uint32_t n_comment_fields;
-    uint32_t reserved2;
+    uint32_t pipeline_depth;      /* batches in flight per writer (device-side frame assembly): each on
+                                     a context, HIP stream and pinned staging buffers of its own, so
+                                     that upload, kernels, download and the MD5 of neighbouring
+                                     batches overlap; 0 = default (2), at most 4 */
 } flacenc_options;
 
 void flacenc_options_default(flacenc_options *o); /* Options::default(), encode.rs:1376-1408 */

@@ -1,0 +1,94 @@
+"""The asynchronous host path (flacgpu_encode_packed_async / frames_ready / fetch_frames_async /
+wait): PCM uploaded at its stream width -- the little-endian bytes FlacByteWriter::write receives
+and update_md5 hashes (/root/reference/src/encode.rs:359, 1292-1318) -- and widened by K0 on the
+device must give exactly the oracle's frame bytes; and the pipelined writers built on it (several
+batches in flight, MD5 on its own thread) exactly the oracle's .flac."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import synth_fast
+
+pytestmark = pytest.mark.gpu
+
+
+def le_bytes(pcm, width):
+    a = np.asarray(pcm, dtype="<i4").view(np.uint8).reshape(-1, 4)
+    return np.ascontiguousarray(a[:, :width]).reshape(-1)
+
+
+def run_packed(pcm, channels, bps, block_size=4096, max_po=6, max_lpc=12, rate=48000, first_frame=7,
+               pinned=True):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    frames = planar_frames(pcm, channels, block_size)
+    n_frames, last = len(frames), frames[-1].shape[1]
+    width = (bps + 7) // 8
+    an = GpuAnalyzer(block_size, max_po, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n_frames)
+    used = pcm[: ((n_frames - 1) * block_size + last) * channels]
+    supported = an.packed_input_supported(width)
+    data, off = an.encode_packed(le_bytes(used, width if supported else 4), width if supported else 4,
+                                 n_frames, last, first_frame, rate, pinned=pinned)
+    oopts = orc_options_for(block_size, max_po, max_lpc, True, True)
+    for f, planar in enumerate(frames):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first_frame + f)
+        assert rc == 0
+        assert data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle (width {width}, supported {supported})"
+    an.close()
+    return supported
+
+
+@pytest.mark.parametrize("channels,bps", [(2, 24), (2, 16), (1, 8), (2, 20), (3, 24), (8, 24), (1, 16),
+                                          (5, 16), (6, 12), (2, 32)])
+def test_packed_upload_matches_oracle(channels, bps):
+    pcm = synth_fast(900 + channels * 40 + bps, channels, bps, 4096 * 5 + 777)
+    supported = run_packed(pcm, channels, bps, max_lpc=12 if bps <= 24 else 8)
+    assert supported == (bps <= 24)
+
+
+def test_packed_other_block_sizes_and_pageable_memory():
+    # 1152: a whole number of 16-byte groups for stereo 16-bit; 4608 with 3 channels x 3 bytes too
+    assert run_packed(synth_fast(950, 2, 16, 1152 * 7 + 100), 2, 16, block_size=1152, max_po=3, max_lpc=0)
+    assert run_packed(synth_fast(951, 3, 24, 4608 * 3), 3, 24, block_size=4608, max_po=5, max_lpc=8)
+    # a block that is not a whole number of 16-byte groups is refused (the caller widens on the host)
+    assert not run_packed(synth_fast(952, 1, 8, 1004 * 3), 1, 8, block_size=1004, max_po=2, max_lpc=4)
+    assert run_packed(synth_fast(953, 2, 24, 4096 * 3), 2, 24, pinned=False)
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_pipelined_writer_byte_identical(depth):
+    from flac_codec_amd.encode import FlacByteWriter, FlacSampleWriter, Options
+
+    for (ch, bps, n, chunk) in [(2, 24, 4096 * 37 + 1234, 50000), (2, 16, 4096 * 20, 4096 * 2 * 3 + 1),
+                                (1, 8, 4096 * 9 + 5, 1 << 20), (4, 20, 4096 * 11 + 17, 33333)]:
+        pcm = synth_fast(700 + ch + bps + depth, ch, bps, n)
+        opts = Options.best().batch_frames(8).pipeline_depth(depth)
+        w = FlacSampleWriter(None, opts, 44100, bps, ch, pcm.size)
+        for i in range(0, pcm.size, chunk):
+            w.write(pcm[i:i + chunk])
+        w.finalize()
+        data = w.getvalue()
+        w.close()
+        rc, ref, _ = orc.encode_stream(orc.options("best"), 44100, bps, ch, pcm, total_known=True)
+        assert rc == 0 and data == ref, f"sample writer differs (ch {ch} bps {bps} depth {depth})"
+        # FlacByteWriter on the same PCM as little-endian bytes, total unknown
+        raw = le_bytes(pcm, (bps + 7) // 8).tobytes()
+        bw = FlacByteWriter(None, Options.best().batch_frames(8).pipeline_depth(depth), 44100, bps, ch)
+        for i in range(0, len(raw), 77777):
+            bw.write(raw[i:i + 77777])
+        bw.finalize()
+        bdata = bw.getvalue()
+        bw.close()
+        rc, ref2, _ = orc.encode_stream(orc.options("best"), 44100, bps, ch, pcm, total_known=False)
+        assert rc == 0 and bdata == ref2, f"byte writer differs (ch {ch} bps {bps} depth {depth})"
+
+
+def test_excessive_total_samples_with_batches_in_flight():
+    from flac_codec_amd import encode as E
+
+    pcm = synth_fast(990, 2, 16, 4096 * 12)
+    w = E.FlacSampleWriter(None, E.Options.default().batch_frames(4).pipeline_depth(3), 44100, 16, 2, 4096 * 2 * 6)
+    with pytest.raises(E.ExcessiveTotalSamples):
+        w.write(pcm)
+    w.close()
