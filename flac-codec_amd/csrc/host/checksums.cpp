@@ -66,7 +66,7 @@ inline uint32_t load_le(const uint8_t *p) {
 Md5::Md5() : a_(0x67452301u), b_(0xefcdab89u), c_(0x98badcfeu), d_(0x10325476u) {}
 
 #define MD5_F(x, y, z) ((z) ^ ((x) & ((y) ^ (z))))
-#define MD5_G(x, y, z) ((y) ^ ((z) & ((x) ^ (y))))
+#define MD5_G(x, y, z) (((x) & (z)) + ((y) & ~(z)))
 #define MD5_H(x, y, z) ((x) ^ (y) ^ (z))
 #define MD5_I(x, y, z) ((y) ^ ((x) | ~(z)))
 #define MD5_STEP(f, a, b, c, d, x, t, s) \

@@ -3,7 +3,11 @@
 // batching PCM blocks into the gfx950 analysis (include/flacenc_gpu.h) and doing what the
 // reference keeps sequential: MD5, frame headers, Rice bit-packing, CRC, seek points,
 // metadata.  C ABI: include/flacenc_stream.h.
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#endif
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -39,6 +43,7 @@ constexpr uint64_t kMaxSamples = 68719476736ull;         // Encoder::MAX_SAMPLES
 constexpr uint32_t kMaxFrameSize = (1u << 24) - 1;       // Streaminfo::MAX_FRAME_SIZE
 constexpr size_t kMaxSeekPoints = (1u << 24) / 18;       // SeekTable::MAX_POINTS
 constexpr uint64_t kMaxFrameNumber = (1ull << 36) - 1;   // FrameNumber::MAX_FRAME_NUMBER
+constexpr size_t kDirectFrames = 64;   // blocks in one write call from which they are encoded without staging
 
 // ---- output sink (W: Write + Seek) --------------------------------------------------
 struct Sink {
@@ -46,8 +51,18 @@ struct Sink {
     bool memory = true;
     std::vector<uint8_t> mem;
     size_t mem_pos = 0;
+    // caller-owned buffer (flacenc_encode_many): no growth, no page faults of our own
+    uint8_t *fixed = nullptr;
+    size_t fixed_cap = 0, fixed_len = 0;
 
     int write(const uint8_t *p, size_t n) {
+        if (fixed) {
+            if (mem_pos + n > fixed_cap) return FLACENC_ERR_IO;
+            std::memcpy(fixed + mem_pos, p, n);
+            mem_pos += n;
+            fixed_len = std::max(fixed_len, mem_pos);
+            return 0;
+        }
         if (!memory) return cb.write(cb.user, p, n) ? FLACENC_ERR_IO : 0;
         if (mem_pos + n > mem.size()) mem.resize(mem_pos + n);
         std::memcpy(mem.data() + mem_pos, p, n);
@@ -55,11 +70,15 @@ struct Sink {
         return 0;
     }
     int seek(uint64_t off) {
+        if (fixed) {
+            mem_pos = static_cast<size_t>(off);
+            return 0;
+        }
         if (!memory) return (cb.seek && cb.seek(cb.user, off) == 0) ? 0 : FLACENC_ERR_IO;
         mem_pos = static_cast<size_t>(off);
         return 0;
     }
-    uint64_t start() const { return memory ? 0 : cb.start; }
+    uint64_t start() const { return (memory || fixed) ? 0 : cb.start; }
 };
 
 struct SeekPoint {
@@ -370,27 +389,59 @@ struct Md5Worker {
 };
 
 // interleaved int32 samples -> little-endian samples of `width` bytes (update_md5's byte string,
-// encode.rs:1292-1318; byteorder.rs:60-72)
+// encode.rs:1292-1318; byteorder.rs:60-72).  x86-64 hosts with AVX2 take the shuffle versions
+// (picked once at run time); everything else the portable loops.
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target("avx2"))) size_t pack_le3_avx2(const int32_t *s, size_t count, uint8_t *d) {
+    // 8 samples -> 24 bytes: per 128-bit half, bytes 0-2, 4-6, 8-10, 12-14 move to the front
+    const __m256i sh = _mm256_setr_epi8(0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1,
+                                        0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1);
+    size_t i = 0;
+    // the 16-byte stores overrun each 12-byte group by 4 bytes: stop one group early
+    for (; i + 16 <= count; i += 8) {
+        const __m256i v = _mm256_shuffle_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i)), sh);
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(d + 3 * i), _mm256_castsi256_si128(v));
+        _mm_storeu_si128(reinterpret_cast<__m128i *>(d + 3 * i + 12), _mm256_extracti128_si256(v, 1));
+    }
+    return i;
+}
+__attribute__((target("avx2"))) size_t pack_le2_avx2(const int32_t *s, size_t count, uint8_t *d) {
+    const __m256i sh = _mm256_setr_epi8(0, 1, 4, 5, 8, 9, 12, 13, -1, -1, -1, -1, -1, -1, -1, -1,
+                                        0, 1, 4, 5, 8, 9, 12, 13, -1, -1, -1, -1, -1, -1, -1, -1);
+    size_t i = 0;
+    for (; i + 8 <= count; i += 8) {
+        const __m256i v = _mm256_shuffle_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i)), sh);
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(d + 2 * i), _mm256_castsi256_si128(v));
+        _mm_storel_epi64(reinterpret_cast<__m128i *>(d + 2 * i + 8), _mm256_extracti128_si256(v, 1));
+    }
+    return i;
+}
+bool have_avx2() {
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+#else
+size_t pack_le3_avx2(const int32_t *, size_t, uint8_t *) { return 0; }
+size_t pack_le2_avx2(const int32_t *, size_t, uint8_t *) { return 0; }
+bool have_avx2() { return false; }
+#endif
+
 void pack_le(const int32_t *s, size_t count, unsigned width, uint8_t *d) {
     switch (width) {
     case 1:
         for (size_t i = 0; i < count; i++) d[i] = static_cast<uint8_t>(s[i]);
         break;
     case 2: {
-        uint16_t *o = reinterpret_cast<uint16_t *>(d);
-        for (size_t i = 0; i < count; i++) o[i] = static_cast<uint16_t>(s[i]);   // little-endian hosts only
+        size_t i = have_avx2() ? pack_le2_avx2(s, count, d) : 0;
+        for (; i < count; i++) {
+            const uint32_t v = static_cast<uint32_t>(s[i]);
+            d[2 * i] = static_cast<uint8_t>(v);
+            d[2 * i + 1] = static_cast<uint8_t>(v >> 8);
+        }
         break;
     }
     case 3: {
-        size_t i = 0;
-        uint32_t *o = reinterpret_cast<uint32_t *>(d);
-        for (; i + 4 <= count; i += 4, o += 3) {   // four samples -> three dwords
-            const uint32_t a = static_cast<uint32_t>(s[i]), b = static_cast<uint32_t>(s[i + 1]),
-                           c = static_cast<uint32_t>(s[i + 2]), e = static_cast<uint32_t>(s[i + 3]);
-            o[0] = (a & 0xFFFFFFu) | (b << 24);
-            o[1] = ((b >> 8) & 0xFFFFu) | (c << 16);
-            o[2] = ((c >> 16) & 0xFFu) | (e << 8);
-        }
+        size_t i = have_avx2() ? pack_le3_avx2(s, count, d) : 0;
         for (; i < count; i++) {
             const uint32_t v = static_cast<uint32_t>(s[i]);
             d[3 * i] = static_cast<uint8_t>(v);
@@ -429,7 +480,7 @@ struct flacenc_writer {
     unsigned upload_width = 4;    // bytes per sample across PCIe
     Md5Worker md5_worker;
     int failed = 0;               // first error of an asynchronous batch
-    uint32_t batch_frames = 1024;
+    uint32_t batch_frames = 256;
     unsigned pack_threads = 1;
     // backlog of interleaved samples not yet cut into blocks (FlacSampleWriter::sample_buf)
     std::vector<int32_t> backlog;
@@ -449,6 +500,11 @@ struct flacenc_writer {
     ~flacenc_writer() {
         for (auto &f : inflight) (void)flacgpu_wait(f.lane->gpu);   // nothing may still write into a pooled lane
         for (Lane *l : lanes) lane_pool().give(gpu_key, l);
+    }
+
+    void use_fixed_sink(uint8_t *buf, size_t cap) {
+        sink.fixed = buf;
+        sink.fixed_cap = cap;
     }
 
     // one more lane (context + staging) for this stream shape, from the pool or new
@@ -521,7 +577,7 @@ struct flacenc_writer {
         std::vector<uint8_t> hdr = build_metadata(si, meta);
         metadata_len = hdr.size();
         if (int e = sink.write(hdr.data(), hdr.size())) return e;
-        batch_frames = o.batch_frames ? o.batch_frames : 1024;
+        batch_frames = o.batch_frames ? o.batch_frames : 256;
         unsigned hw = std::thread::hardware_concurrency();
         pack_threads = o.pack_threads ? o.pack_threads : std::max(1u, std::min(hw, 16u));
         flacgpu_options g = gpu_options(o, o.block_size);
@@ -812,18 +868,24 @@ struct flacenc_writer {
     // backlog has been topped up to a whole batch and drained, whole batches are encoded straight
     // from the caller's buffer and only the tail (< one batch) is kept
     int write_direct(const int32_t *samples, size_t count) {
-        const size_t batch_samples = static_cast<size_t>(batch_frames) * o.block_size * si.channels;
+        const size_t frame_samples = static_cast<size_t>(o.block_size) * si.channels;
+        const size_t batch_samples = static_cast<size_t>(batch_frames) * frame_samples;
+        // a call that brings many blocks at once is encoded from the caller's buffer right away, in
+        // batches of at most batch_frames (the last one smaller); small writes accumulate to a batch
+        const bool large = !o.host_pack && count >= kDirectFrames * frame_samples;
         if (!backlog.empty()) {
-            const size_t room = backlog.size() < batch_samples ? batch_samples - backlog.size() : 0;
+            size_t room;
+            if (large) room = (frame_samples - backlog.size() % frame_samples) % frame_samples;  // finish the open block
+            else room = backlog.size() < batch_samples ? batch_samples - backlog.size() : 0;
             const size_t take = std::min(room, count);
             backlog.insert(backlog.end(), samples, samples + take);
             samples += take;
             count -= take;
-            if (int rc = drain(false)) return rc;
+            if (int rc = drain(large)) return rc;
         }
-        if (backlog.empty() && count >= batch_samples) {
+        if (backlog.empty() && (large || count >= batch_samples)) {
             size_t consumed = 0;
-            if (int rc = process(samples, count, false, &consumed)) return rc;
+            if (int rc = process(samples, count, large, &consumed)) return rc;
             samples += consumed;
             count -= consumed;
         }
@@ -908,7 +970,8 @@ struct flacenc_writer {
         }
         if (int e = sink.seek(sink.start())) return e;
         if (int e = sink.write(hdr.data(), hdr.size())) return e;
-        if (sink.memory) sink.mem_pos = sink.mem.size();
+        if (sink.fixed) sink.mem_pos = sink.fixed_len;
+        else if (sink.memory) sink.mem_pos = sink.mem.size();
         stats.frames = frame_number;
         stats.samples_per_channel = samples_written;
         stats.bytes_written = metadata_len + byte_count;
@@ -1094,6 +1157,54 @@ int flacenc_pack_frames(uint32_t sample_rate, uint32_t bps, uint32_t channels,
     for (uint32_t f = 0; f <= n_frames; f++) offsets[f] = pb.offsets[f];
     if (!out || cap < pb.bytes.size()) return FLACENC_ERR_INVALID_ARG;
     std::memcpy(out, pb.bytes.data(), pb.bytes.size());
+    return 0;
+}
+
+// Many independent streams at once (a music library): `threads` workers, each driving one stream at
+// a time through FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) into the job's own
+// output buffer; the GPU is shared through the pooled lanes, the MD5 chains run on the writers'
+// worker threads.
+int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
+    if (!opts || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
+    if (int e = options_error(*opts)) return e;
+    std::atomic<size_t> next{0};
+    const double t_begin = now_ms();
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_jobs) return;
+            flacenc_job &j = jobs[i];
+            j.out_len = 0;
+            if (!j.samples || !j.out || j.bits_per_sample < 1 || j.bits_per_sample > 32 || j.channels == 0 ||
+                j.count % j.channels || j.count == 0) {
+                j.status = FLACENC_ERR_INVALID_ARG;
+                continue;
+            }
+            const double t0 = now_ms();
+            std::unique_ptr<flacenc_writer> w(new flacenc_writer());
+            w->kind = flacenc_writer::SAMPLE;
+            w->use_fixed_sink(j.out, j.out_cap);
+            int rc = w->init(*opts, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
+            if (!rc) rc = w->write_direct(j.samples, j.count);
+            if (!rc) rc = w->finalize();
+            j.status = rc;
+            j.out_len = w->sink.fixed_len;
+            j.start_ms = t0 - t_begin;
+            j.elapsed_ms = now_ms() - t0;
+            j.pack_ms = w->stats.pack_ms;
+            j.gpu_ms = w->stats.gpu_ms;
+            j.md5_ms = w->stats.md5_ms;
+        }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = threads ? threads : std::min<unsigned>(hw / 2 ? hw / 2 : 1, 64);
+    nt = static_cast<unsigned>(std::min<size_t>(nt, std::max<size_t>(1, n_jobs)));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    for (size_t i = 0; i < n_jobs; i++)
+        if (jobs[i].status) return jobs[i].status;
     return 0;
 }
 

@@ -118,6 +118,27 @@ class Stats(C.Structure):
     ]
 
 
+class _CJob(C.Structure):
+    _fields_ = [
+        ("samples", C.POINTER(C.c_int32)),
+        ("count", C.c_size_t),
+        ("sample_rate", C.c_uint32),
+        ("bits_per_sample", C.c_uint32),
+        ("channels", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("out", C.c_void_p),
+        ("out_cap", C.c_size_t),
+        ("out_len", C.c_size_t),
+        ("status", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("elapsed_ms", C.c_double),
+        ("pack_ms", C.c_double),
+        ("gpu_ms", C.c_double),
+        ("md5_ms", C.c_double),
+        ("start_ms", C.c_double),
+    ]
+
+
 _bound = False
 _bind_lock = threading.Lock()
 
@@ -161,6 +182,7 @@ def _stream_lib():
         L.flacenc_stream_writer_free.argtypes = [vp]
         L.flacenc_stream_writer_free.restype = None
         L.flacenc_last_error.restype = C.c_char_p
+        L.flacenc_encode_many.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32]
         _bound = True
     return L
 
@@ -527,3 +549,38 @@ class FlacStreamWriter:
             self.close()
         except Exception:
             pass
+
+
+class BatchEncoder:
+    """Many independent streams at once (flacenc_encode_many): the C++ front end keeps `threads` host
+    workers busy, each running FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) for
+    one stream at a time; output buffers are allocated once and reused by later calls."""
+
+    def __init__(self, options, threads=0):
+        self._opts, self._threads = options, threads
+        self._bufs = []
+
+    def encode(self, streams, sample_rate, bits_per_sample, channels, copy=True):
+        """streams: list of interleaved int32 arrays.  Returns the .flac bytes of every stream (or
+        memoryviews into the reused output buffers with copy=False)."""
+        L = _stream_lib()
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in streams]
+        jobs = (_CJob * len(arrs))()
+        width = (bits_per_sample + 7) // 8
+        for i, a in enumerate(arrs):
+            cap = a.size * width + a.size // 16 + (1 << 16)
+            if i >= len(self._bufs):
+                self._bufs.append(np.empty(cap, dtype=np.uint8))
+            elif self._bufs[i].size < cap:
+                self._bufs[i] = np.empty(cap, dtype=np.uint8)
+            j = jobs[i]
+            j.samples = a.ctypes.data_as(C.POINTER(C.c_int32))
+            j.count = a.size
+            j.sample_rate, j.bits_per_sample, j.channels = sample_rate, bits_per_sample, channels
+            j.out = self._bufs[i].ctypes.data
+            j.out_cap = self._bufs[i].size
+        _check(L.flacenc_encode_many(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+        self.last_jobs = [{k: getattr(jobs[i], k) for k in ("elapsed_ms", "pack_ms", "gpu_ms", "md5_ms", "start_ms")}
+                          for i in range(len(arrs))]
+        views = [self._bufs[i][: jobs[i].out_len] for i in range(len(arrs))]
+        return [v.tobytes() for v in views] if copy else views

@@ -76,7 +76,7 @@ typedef struct {
     int32_t seektable_mode;       /* FLACENC_SEEKTABLE_* (encode.rs:1568-1590) */
     uint32_t seektable_value;     /* seconds (u8) or frames */
     /* execution knobs (no reference equivalent) */
-    uint32_t batch_frames;        /* FLAC frames analysed per GPU call; 0 = default (1024) */
+    uint32_t batch_frames;        /* FLAC frames analysed per GPU call; 0 = default (256: small enough that a stream's first batch reaches the MD5 thread and the GPU within ~2 ms) */
     int32_t device;               /* HIP device ordinal, -1 = current */
     uint32_t pack_threads;        /* host bit-pack threads; 0 = default */
     uint32_t host_pack;           /* 0: frames are assembled on the GPU (k_layout/k_pack/k_crc);
@@ -148,6 +148,28 @@ void flacenc_writer_free(flacenc_writer *w);
 
 /* memory sink access (sink == NULL at creation) */
 const uint8_t *flacenc_writer_data(flacenc_writer *w, size_t *len);
+
+/* Batch front end: many independent streams encoded concurrently by `threads` host workers (0 =
+ * default), each one FlacSampleWriter::new(total known) / write / finalize (encode.rs:487, 558, 624)
+ * with the .flac bytes written to the job's own buffer (FLACENC_ERR_IO in `status` when it is too
+ * small; the PCM size at stream width plus the metadata is always enough).  The workers share the
+ * GPU through the pooled analysis lanes; every stream's MD5 chain runs on a thread of its own.
+ * Returns 0 or the first job's error. */
+typedef struct {
+    const int32_t *samples;   /* interleaved, the whole stream */
+    size_t count;             /* samples over all channels */
+    uint32_t sample_rate, bits_per_sample, channels;
+    uint32_t reserved;
+    uint8_t *out;             /* caller-owned output buffer */
+    size_t out_cap;
+    size_t out_len;           /* out: bytes of the finished stream */
+    int32_t status;           /* out: FLACENC_OK or the error of this stream */
+    int32_t reserved1;
+    /* out, diagnostics: wall time of this stream on its worker, and inside it the staging
+     * (sample packing), the GPU calls incl. waiting for results, and the MD5 thread's busy time */
+    double elapsed_ms, pack_ms, gpu_ms, md5_ms, start_ms;
+} flacenc_job;
+int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads);
 
 /* FlacStreamWriter (encode.rs:1050-1290): header-less subset frames, parameters per call. */
 typedef struct flacenc_stream_writer flacenc_stream_writer;

@@ -92,3 +92,16 @@ def test_excessive_total_samples_with_batches_in_flight():
     with pytest.raises(E.ExcessiveTotalSamples):
         w.write(pcm)
     w.close()
+
+
+def test_batch_front_end_matches_oracle():
+    """flacenc_encode_many: streams of different lengths, more streams than worker threads."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    streams = [synth_fast(1200 + i, 2, 16, 4096 * (3 + 5 * i) + 100 * i) for i in range(7)]
+    be = BatchEncoder(Options.default().batch_frames(16), threads=3)
+    for rep in range(2):   # the second call reuses lanes and output buffers
+        outs = be.encode(streams, 44100, 16, 2)
+        for s, o in zip(streams, outs):
+            rc, ref, _ = orc.encode_stream(orc.options("default"), 44100, 16, 2, s, total_known=True)
+            assert rc == 0 and o == ref
