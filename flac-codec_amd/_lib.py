@@ -74,6 +74,18 @@ class VerifyResult(C.Structure):
     ]
 
 
+class StreamInfo(C.Structure):
+    """flacgpu_stream_info."""
+    _fields_ = [
+        ("sample_rate", C.c_uint32), ("channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
+        ("min_block", C.c_uint32), ("max_block", C.c_uint32),
+        ("frames", C.c_uint32), ("bad_frames", C.c_uint32), ("bad_crc16", C.c_uint32),
+        ("total_samples", C.c_uint64), ("decoded_samples", C.c_uint64),
+        ("md5", C.c_uint8 * 16), ("decoded_md5", C.c_uint8 * 16),
+        ("md5_status", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
 class GpuStats(C.Structure):
     _fields_ = [
         ("frames", C.c_uint32),
@@ -139,6 +151,9 @@ def _load():
     L.flacenc_pack_frames.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, ip, C.c_uint32,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.flacgpu_decode_stream.argtypes = [C.c_char_p, C.c_size_t, C.c_int, ip, C.c_size_t, C.POINTER(StreamInfo)]
+    L.flacgpu_pack_plans.argtypes = [vp, ip, C.c_uint32, C.c_uint32, C.POINTER(FramePlan), C.POINTER(SubframePlan),
+                                     C.c_uint64, C.c_uint32]
     L.flacgpu_host_alloc.argtypes = [C.c_size_t]
     L.flacgpu_host_alloc.restype = vp
     L.flacgpu_host_free.argtypes = [vp]

@@ -25,7 +25,17 @@ void launch_decode(uint32_t mo, uint32_t units, uint32_t lanes, const Params &pd
     else hipLaunchKernelGGL(k_decode<32>, grid, block, 0, st, pd, q, decoded, verify_counts);
 }
 void launch_decode_finish(const Params &p, int32_t *decoded, const int32_t *expect, uint32_t *verify_counts,
-                          hipStream_t st) {
-    hipLaunchKernelGGL(k_decode_finish, dim3(p.n_frames), dim3(WG), 0, st, p, decoded, expect, verify_counts);
+                          hipStream_t st, const uint32_t *frame_n) {
+    hipLaunchKernelGGL(k_decode_finish, dim3(p.n_frames), dim3(WG), 0, st, p, decoded, expect, verify_counts,
+                       frame_n);
+}
+// stand-alone decode: one lane per frame, 32-lane waves (see launch_decode), any LPC order
+void launch_decode_frames(const uint32_t *words, const uint64_t *frame_off, const uint32_t *frame_n,
+                          uint64_t cap_bytes, uint32_t n_frames, uint32_t channels, uint32_t bps, uint32_t ldb,
+                          int32_t *decoded, uint32_t *verify_counts, hipStream_t st) {
+    DecodeParams dp{words, frame_off, frame_n, cap_bytes, n_frames, channels, bps, ldb};
+    const uint32_t lanes = 32;
+    hipLaunchKernelGGL(k_decode_frames<32>, dim3((n_frames + lanes - 1) / lanes), dim3(lanes), 0, st, dp, decoded,
+                       verify_counts);
 }
 }  // namespace flacgpu_k

@@ -29,6 +29,7 @@
 //         generic: k_zero + k_pack + k_crc
 //   N3    k_decode (decode.inc)  decode.rs:1388-1856 read_frame .. predict, one lane per subframe
 #include "kernels/types.h"
+#include "checksums.h"
 
 #include <math.h>
 #include <stdint.h>
@@ -901,6 +902,278 @@ int flacgpu_encode_frames(flacgpu_ctx *c, const int32_t *pcm, int layout, uint32
                                    c->own_stream);
     if (rc) return rc;
     return flacgpu_fetch_frames(c, out, cap, offsets, total);
+}
+
+// Frame assembly of caller-supplied decisions: the device-side counterpart of flacenc_pack_frames.
+// The PCM is split into planar rows as for an analysis, the plans replace the ones an analysis would
+// have produced, and the packers (k_frame64, or k_emit + k_pack + k_crc) run on them.
+int flacgpu_pack_plans(flacgpu_ctx *c, const int32_t *pcm, uint32_t n_frames, uint32_t last_len,
+                       const flacgpu_frame_plan *plans, const flacgpu_subframe_plan *subs,
+                       uint64_t first_frame_number, uint32_t sample_rate) {
+    if (!c || !pcm || !plans || !subs || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
+        last_len > c->opts.block_size) {
+        g_last_error = "flacgpu_pack_plans: invalid arguments";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    hipStream_t st = c->own_stream;
+    const size_t B = c->opts.block_size, C = c->channels;
+    const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
+    HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st));
+    (void)launch_k0(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, 0, n_frames, st);
+    HIP_TRY(hipMemcpyAsync(c->d_fplan, plans, sizeof(*plans) * n_frames, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_out, subs, sizeof(*subs) * n_frames * C, hipMemcpyHostToDevice, st));
+    Params p;
+    fill_params(c, n_frames, last_len, p);
+    c->last_params = p;
+    c->last_frames = n_frames;
+    c->last_len = last_len;
+    c->last_stream = st;
+    c->resid_valid = false;
+    c->packed_valid = false;
+    HIP_TRY(hipStreamSynchronize(st));   // the host arrays may go away
+    return pack_impl(c, first_frame_number, sample_rate, st, nullptr);
+}
+
+// ---- stand-alone decoder: any FLAC stream (fLaC marker, metadata, frames) --------------------
+namespace {
+struct HostFrameHead {
+    uint32_t n = 0, header_bytes = 0, blocking = 0, acode = 0, bps_code = 0;
+};
+// FrameHeader::parse (stream.rs:214-240) on the host: used by the scan for frame starts
+bool host_parse_header(const uint8_t *d, size_t avail, HostFrameHead &h) {
+    if (avail < 6 || d[0] != 0xFF || (d[1] & 0xFE) != 0xF8) return false;
+    h.blocking = d[1] & 1;
+    const uint32_t bcode = d[2] >> 4, rcode = d[2] & 15;
+    h.acode = d[3] >> 4;
+    h.bps_code = (d[3] >> 1) & 7;
+    if ((d[3] & 1) || h.acode > 10 || bcode == 0 || rcode == 15 || h.bps_code == 3) return false;
+    size_t k = 4;
+    {   // UTF-8 like number
+        const uint8_t b0 = d[k];
+        uint32_t ones = 0;
+        while (ones < 8 && (b0 & (0x80 >> ones))) ones++;
+        if (ones == 1 || ones > 7) return false;
+        const uint32_t extra = ones ? ones - 1 : 0;
+        if (k + 1 + extra > avail) return false;
+        for (uint32_t i = 1; i <= extra; i++)
+            if ((d[k + i] & 0xC0) != 0x80) return false;
+        k += 1 + extra;
+    }
+    switch (bcode) {
+    case 1: h.n = 192; break;
+    case 2: h.n = 576; break;
+    case 3: h.n = 1152; break;
+    case 4: h.n = 2304; break;
+    case 5: h.n = 4608; break;
+    case 6:
+        if (k + 1 > avail) return false;
+        h.n = d[k] + 1u;
+        k += 1;
+        break;
+    case 7:
+        if (k + 2 > avail) return false;
+        h.n = ((uint32_t)d[k] << 8 | d[k + 1]) + 1u;
+        k += 2;
+        break;
+    default: h.n = 256u << (bcode - 8); break;
+    }
+    if (rcode == 12) k += 1;
+    else if (rcode == 13 || rcode == 14) k += 2;
+    if (k + 1 > avail) return false;
+    if (flacenc::crc8(d, k) != d[k]) return false;
+    h.header_bytes = (uint32_t)k + 1;
+    return true;
+}
+}  // namespace
+
+// Decodes a whole FLAC stream held in host memory.  The host finds the frame boundaries (a frame
+// ends where the next valid header -- sync code, CRC-8 -- begins AND the two bytes before it are
+// the CRC-16 of everything since the frame's start; the last frame ends with the stream), the GPU
+// decodes the frames in parallel, one lane per frame, re-checks every CRC-16 and undoes the stereo
+// decorrelation; the MD5 of the decoded PCM is compared with STREAMINFO's on the host
+// (decode.rs:1282 `verify`, 1388-1436 read_frame, 1494-1856).
+int flacgpu_decode_stream(const uint8_t *data, size_t len, int device, int32_t *out, size_t out_cap,
+                          flacgpu_stream_info *info) {
+    if (!data || !info) return FLACGPU_ERR_INVALID_ARG;
+    memset(info, 0, sizeof *info);
+    if (len < 42 || memcmp(data, "fLaC", 4) != 0) {
+        g_last_error = "not a FLAC stream (no fLaC marker)";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    size_t pos = 4;
+    bool have_si = false;
+    uint32_t min_frame = 0;
+    for (;;) {   // metadata blocks (metadata/mod.rs:257-266): last flag + type, 24-bit length
+        if (pos + 4 > len) return FLACGPU_ERR_INVALID_ARG;
+        const bool last = data[pos] & 0x80;
+        const uint32_t type = data[pos] & 0x7F;
+        const size_t blen = (size_t)data[pos + 1] << 16 | (size_t)data[pos + 2] << 8 | data[pos + 3];
+        pos += 4;
+        if (pos + blen > len) return FLACGPU_ERR_INVALID_ARG;
+        if (type == 0 && blen == 34) {   // STREAMINFO, metadata/mod.rs:1599-1630
+            const uint8_t *b = data + pos;
+            info->min_block = b[0] << 8 | b[1];
+            info->max_block = b[2] << 8 | b[3];
+            min_frame = b[4] << 16 | b[5] << 8 | b[6];
+            info->sample_rate = (uint32_t)b[10] << 12 | (uint32_t)b[11] << 4 | b[12] >> 4;
+            info->channels = ((b[12] >> 1) & 7) + 1;
+            info->bits_per_sample = (((uint32_t)b[12] & 1) << 4 | b[13] >> 4) + 1;
+            info->total_samples = ((uint64_t)(b[13] & 15) << 32) | (uint64_t)b[14] << 24 | (uint64_t)b[15] << 16 |
+                                  (uint64_t)b[16] << 8 | b[17];
+            memcpy(info->md5, b + 18, 16);
+            have_si = true;
+        }
+        pos += blen;
+        if (last) break;
+    }
+    if (!have_si || info->channels > 8 || info->bits_per_sample > 32 || info->max_block < 1) {
+        g_last_error = "no usable STREAMINFO block";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    // ---- scan for frame starts
+    uint16_t T[256];
+    for (int i = 0; i < 256; i++) {
+        uint16_t c = (uint16_t)(i << 8);
+        for (int b = 0; b < 8; b++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
+        T[i] = c;
+    }
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> fn;
+    size_t p = pos;
+    uint64_t samples = 0;
+    uint32_t bad_scan = 0;
+    while (p < len) {
+        HostFrameHead h;
+        if (!host_parse_header(data + p, len - p, h)) {
+            bad_scan++;
+            break;   // lost synchronisation: what follows is not decoded
+        }
+        // running CRC-16 from p; crc_m2 = CRC over [p, i - 2)
+        uint16_t crc = 0, d1 = 0, d2 = 0;   // crc after i bytes, i-1 bytes, i-2 bytes
+        size_t q = p;
+        size_t end = 0;
+        const size_t min_end = p + std::max<size_t>(h.header_bytes + 2 + info->channels, min_frame ? min_frame : 0);
+        for (; q < len; q++) {
+            if (q >= min_end && q >= p + 2) {
+                // candidate: a header starts at q and bytes [q-2, q) are the CRC-16 of [p, q-2)
+                if (data[q] == 0xFF && (data[q + (q + 1 < len ? 1 : 0)] & 0xFE) == 0xF8 &&
+                    (uint16_t)(data[q - 2] << 8 | data[q - 1]) == d2) {
+                    HostFrameHead hn;
+                    if (host_parse_header(data + q, len - q, hn) && hn.blocking == h.blocking) {
+                        end = q;
+                        break;
+                    }
+                }
+            }
+            d2 = d1;
+            d1 = crc;
+            crc = (uint16_t)(T[(crc >> 8) ^ data[q]] ^ (crc << 8));
+        }
+        if (!end) {   // the last frame ends with the stream
+            if (q == len && len >= p + 2 && (uint16_t)(data[len - 2] << 8 | data[len - 1]) == d2) end = len;
+            else {
+                bad_scan++;
+                break;
+            }
+        }
+        off.push_back(p);
+        fn.push_back(h.n);
+        samples += h.n;
+        p = end;
+    }
+    off.push_back(p);
+    const size_t F = fn.size();
+    info->frames = (uint32_t)F;
+    info->bad_frames = bad_scan;
+    info->decoded_samples = samples;
+    const size_t C = info->channels;
+    if (F == 0) return FLACGPU_OK;
+    if (out && out_cap < samples * C) {
+        g_last_error = "output buffer too small";
+        return FLACGPU_ERR_BUFFER_TOO_SMALL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_last_error = "no HIP device";
+        return FLACGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    DeviceGuard guard(device);
+    uint32_t maxn = 0;
+    for (uint32_t v : fn) maxn = std::max(maxn, v);
+    const size_t ldb = (maxn + 3u) & ~3u;
+    // ---- device buffers (freed on every path by the guard object below)
+    struct Bufs {
+        void *bytes = nullptr, *off = nullptr, *fn = nullptr, *pcm = nullptr, *counts = nullptr;
+        hipStream_t st = nullptr;
+        ~Bufs() {
+            (void)hipFree(bytes); (void)hipFree(off); (void)hipFree(fn); (void)hipFree(pcm); (void)hipFree(counts);
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } b;
+    const size_t bytes_cap = (len + 64 + 3) & ~(size_t)3;
+    HIP_TRY(hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&b.bytes, bytes_cap));
+    HIP_TRY(hipMalloc(&b.off, sizeof(uint64_t) * (F + 1)));
+    HIP_TRY(hipMalloc(&b.fn, sizeof(uint32_t) * F));
+    HIP_TRY(hipMalloc(&b.pcm, sizeof(int32_t) * (F * C * ldb + 64)));
+    HIP_TRY(hipMalloc(&b.counts, sizeof(uint32_t) * (4 + F)));
+    HIP_TRY(hipMemsetAsync(b.bytes, 0, bytes_cap, b.st));
+    HIP_TRY(hipMemcpyAsync(b.bytes, data, len, hipMemcpyHostToDevice, b.st));
+    HIP_TRY(hipMemcpyAsync(b.off, off.data(), sizeof(uint64_t) * (F + 1), hipMemcpyHostToDevice, b.st));
+    HIP_TRY(hipMemcpyAsync(b.fn, fn.data(), sizeof(uint32_t) * F, hipMemcpyHostToDevice, b.st));
+    HIP_TRY(hipMemsetAsync(b.counts, 0, sizeof(uint32_t) * (4 + F), b.st));
+    launch_decode_frames((const uint32_t *)b.bytes, (const uint64_t *)b.off, (const uint32_t *)b.fn, bytes_cap,
+                         (uint32_t)F, (uint32_t)C, info->bits_per_sample, (uint32_t)ldb, (int32_t *)b.pcm,
+                         (uint32_t *)b.counts, b.st);
+    Params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.channels = (uint32_t)C;
+    pp.bps = info->bits_per_sample;
+    pp.block_size = maxn;
+    pp.ldb = (uint32_t)ldb;
+    pp.n_frames = (uint32_t)F;
+    pp.last_len = fn[F - 1];
+    pp.fcount = (uint32_t)F;
+    PackParams q;
+    q.first_frame_number = 0;
+    q.sample_rate = info->sample_rate;
+    q.out_words = (uint32_t *)b.bytes;
+    q.frame_off = (uint64_t *)b.off;
+    q.cap_bytes = bytes_cap;
+    launch_crc(true, pp, q, (uint32_t)F, (uint32_t *)b.counts, b.st);
+    launch_decode_finish(pp, (int32_t *)b.pcm, nullptr, (uint32_t *)b.counts, b.st, (const uint32_t *)b.fn);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> planar(F * C * ldb);
+    uint32_t counts[4];
+    HIP_TRY(hipMemcpyAsync(planar.data(), b.pcm, sizeof(int32_t) * planar.size(), hipMemcpyDeviceToHost, b.st));
+    HIP_TRY(hipMemcpyAsync(counts, b.counts, sizeof counts, hipMemcpyDeviceToHost, b.st));
+    HIP_TRY(hipStreamSynchronize(b.st));
+    info->bad_frames += counts[0];
+    info->bad_crc16 = counts[1];
+    // interleave + MD5 over ceil(bps / 8)-byte little-endian samples (decode.rs:1282 verify)
+    flacenc::Md5 md5;
+    const unsigned width = (info->bits_per_sample + 7) / 8;
+    std::vector<uint8_t> le(maxn * C * width);
+    size_t o = 0;
+    for (size_t f = 0; f < F; f++) {
+        const size_t n = fn[f];
+        size_t k = 0;
+        for (size_t i = 0; i < n; i++)
+            for (size_t ch = 0; ch < C; ch++) {
+                const int32_t v = planar[(f * C + ch) * ldb + i];
+                if (out) out[o++] = v;
+                for (unsigned w = 0; w < width; w++) le[k++] = (uint8_t)((uint32_t)v >> (8 * w));
+            }
+        md5.update(le.data(), k);
+    }
+    uint8_t got[16], zero[16] = {0};
+    md5.digest(got);
+    memcpy(info->decoded_md5, got, 16);
+    info->md5_status = memcmp(info->md5, zero, 16) == 0 ? 2 : (memcmp(info->md5, got, 16) == 0 ? 1 : 0);
+    return FLACGPU_OK;
 }
 
 // ---- asynchronous host path ------------------------------------------------------------------

@@ -1208,6 +1208,29 @@ int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n
     return 0;
 }
 
+// The 34 bytes of a STREAMINFO block body (metadata/mod.rs:1599-1630, 1740-1760) as the writers
+// serialise them: exposed so that the layout can be checked against the reference's literal bytes.
+int flacenc_streaminfo_bytes(uint32_t min_block, uint32_t max_block, uint32_t min_frame, uint32_t max_frame,
+                             uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample,
+                             uint64_t total_samples, const uint8_t md5[16], uint8_t out[34]) {
+    if (!md5 || !out) return FLACENC_ERR_INVALID_ARG;
+    StreamInfo si;
+    si.min_block = min_block;
+    si.max_block = max_block;
+    si.min_frame = min_frame;
+    si.max_frame = max_frame;
+    si.sample_rate = sample_rate;
+    si.channels = channels;
+    si.bps = bits_per_sample;
+    si.total_samples = total_samples;
+    std::memcpy(si.md5, md5, 16);
+    MetaLayout m;
+    const std::vector<uint8_t> v = build_metadata(si, m);   // "fLaC" + header (4) + body (34)
+    if (v.size() != 42) return FLACENC_ERR_IO;
+    std::memcpy(out, v.data() + 8, 34);
+    return 0;
+}
+
 int flacenc_writer_stats(flacenc_writer *w, flacenc_stats *out) {
     if (!w || !out) return FLACENC_ERR_INVALID_ARG;
     *out = w->stats;

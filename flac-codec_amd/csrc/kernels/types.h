@@ -135,6 +135,9 @@ void launch_frame64_short(const Params &p, const PackParams &q, uint32_t B, uint
 void launch_decode(uint32_t max_lpc_order, uint32_t units, uint32_t lanes, const Params &p, const PackParams &q,
                    int32_t *decoded, uint32_t *verify_counts, hipStream_t st);
 void launch_decode_finish(const Params &p, int32_t *decoded, const int32_t *expect, uint32_t *verify_counts,
-                          hipStream_t st);
+                          hipStream_t st, const uint32_t *frame_n = nullptr);
+void launch_decode_frames(const uint32_t *words, const uint64_t *frame_off, const uint32_t *frame_n,
+                          uint64_t cap_bytes, uint32_t n_frames, uint32_t channels, uint32_t bps, uint32_t ldb,
+                          int32_t *decoded, uint32_t *verify_counts, hipStream_t st);
 }  // namespace flacgpu_k
 #endif

@@ -231,6 +231,25 @@ class GpuAnalyzer:
                 if arr[i] > 0}
 
 
+def decode_stream(data, device=-1, want_pcm=True):
+    """Stand-alone GPU decode + verify of a whole FLAC stream (flacgpu_decode_stream): returns
+    (interleaved int32 PCM or None, StreamInfo)."""
+    L = _lib.lib()
+    info = _lib.StreamInfo()
+    data = bytes(data)
+    rc = L.flacgpu_decode_stream(data, len(data), device, None, 0, C.byref(info))   # sizes + verification
+    if rc:
+        raise GpuError(rc, "flacgpu_decode_stream")
+    if not want_pcm:
+        return None, info
+    out = np.empty(info.decoded_samples * info.channels, dtype=np.int32)
+    rc = L.flacgpu_decode_stream(data, len(data), device, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size,
+                                 C.byref(info))
+    if rc:
+        raise GpuError(rc, "flacgpu_decode_stream")
+    return out, info
+
+
 def host_pack_frames(sample_rate, bits_per_sample, channels, first_frame_number, n_frames,
                      row_stride, plans, subs, rows, threads=1):
     """Host bit-packing of an analysed batch (flacenc_pack_frames); returns (bytes, offsets)."""

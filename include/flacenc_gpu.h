@@ -213,6 +213,15 @@ int flacgpu_encode_frames(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint
                           uint32_t sample_rate, uint8_t *out, size_t cap, uint64_t *offsets,
                           uint64_t *total);
 
+/* Device-side frame assembly of CALLER-SUPPLIED decisions (the device counterpart of
+ * flacenc_pack_frames, include/flacenc_stream.h): `pcm` (host, interleaved, as for flacgpu_analyze)
+ * is split into rows, `plans` [n_frames] / `subframes` [n_frames * channels] replace what an analysis
+ * would have decided, and the packers produce the frame bytes (flacgpu_fetch_frames).  The decisions
+ * must be consistent with the PCM (residuals are recomputed from it). */
+int flacgpu_pack_plans(flacgpu_ctx *ctx, const int32_t *pcm, uint32_t n_frames, uint32_t last_frame_len,
+                       const flacgpu_frame_plan *plans, const flacgpu_subframe_plan *subframes,
+                       uint64_t first_frame_number, uint32_t sample_rate);
+
 /* ---- asynchronous host path: stream-width upload, sizes ahead of the bytes ---------------------
  * What a streaming front end (FlacSampleWriter / FlacByteWriter, encode.rs:359, 558) needs to keep
  * several batches in flight: PCM enters as the little-endian `bytes_per_sample = ceil(bps / 8)`-byte
@@ -265,6 +274,28 @@ int flacgpu_verify_device(flacgpu_ctx *ctx, uint32_t sample_rate, uint64_t first
 /* decoded PCM of the last flacgpu_verify_device, interleaved, to host memory
  * ((n_frames-1)*block_size + last_frame_len) * channels samples */
 int flacgpu_fetch_decoded(flacgpu_ctx *ctx, int32_t *interleaved);
+
+/* ---- stand-alone decoder: any FLAC stream, not only this encoder's output ---------------------
+ * The reference's `verify` / frame reader (decode.rs:1282, 1388-1436 read_frame, 1494-1856) for a
+ * whole stream held in host memory: the host parses the metadata and finds the frame boundaries
+ * (next valid header preceded by the CRC-16 of everything since the frame's start), the GPU decodes
+ * the frames in parallel (one lane per frame walks its subframes front to back), re-checks every
+ * CRC-16 and undoes the stereo decorrelation; the MD5 of the decoded PCM is compared with
+ * STREAMINFO's.  `out` (may be NULL: verify only) receives the interleaved samples. */
+typedef struct {
+    uint32_t sample_rate, channels, bits_per_sample, min_block, max_block;
+    uint32_t frames;            /* frames found by the scan */
+    uint32_t bad_frames;        /* frames that did not parse (+1 when the scan lost synchronisation) */
+    uint32_t bad_crc16;
+    uint64_t total_samples;     /* STREAMINFO: samples per channel, 0 = unknown */
+    uint64_t decoded_samples;   /* samples per channel in the frames found */
+    uint8_t md5[16];            /* STREAMINFO */
+    uint8_t decoded_md5[16];    /* of the decoded PCM */
+    uint32_t md5_status;        /* 1: equal, 0: different, 2: STREAMINFO holds no MD5 (all zero) */
+    uint32_t reserved;
+} flacgpu_stream_info;
+int flacgpu_decode_stream(const uint8_t *data, size_t len, int device, int32_t *out, size_t out_cap_samples,
+                          flacgpu_stream_info *info);
 
 /* EXPERIMENT, not on the product path: recomputes the autocorrelation of the last analysed
  * batch on the f64 matrix cores (v_mfma_f64_16x16x4_f64, block-Gram form), times that kernel,

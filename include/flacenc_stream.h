@@ -201,6 +201,11 @@ int flacenc_pack_frames(uint32_t sample_rate, uint32_t bits_per_sample, uint32_t
                         const int32_t *residual_rows, uint32_t threads, uint8_t *out, size_t cap,
                         uint64_t *offsets);
 
+/* The 34-byte STREAMINFO body exactly as the writers serialise it (metadata/mod.rs:1599-1630). */
+int flacenc_streaminfo_bytes(uint32_t min_block, uint32_t max_block, uint32_t min_frame, uint32_t max_frame,
+                             uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample,
+                             uint64_t total_samples, const uint8_t md5[16], uint8_t out[34]);
+
 const char *flacenc_last_error(void);
 
 #ifdef __cplusplus

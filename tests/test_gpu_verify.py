@@ -2,10 +2,12 @@
 packed, without leaving HBM, and must give back the input PCM; corrupting one byte of a frame
 must be detected (the reference's tests/corruption.rs does the same with random bit flips)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
+import _oracle as orc
 from _pcm import read_raw, synth_fast
 
 pytestmark = pytest.mark.gpu
@@ -116,3 +118,49 @@ def test_heavy_corruption_never_hangs_or_spills_over(ch, bps, block, lpc):
     res, _ = an.verify_device(48000)
     assert (res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (0, 0, 0)
     an.close()
+
+
+# ---- stand-alone decoder (flacgpu_decode_stream): foreign streams, no encoder plan ---------------
+REFDATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdata")
+
+
+@pytest.mark.parametrize("name,md5hex", [("sine.flac", "831671b807f97051301e01d68b5c54b3"),
+                                          ("all-frames.flac", None), ("seektable.flac", None),
+                                          ("comment.flac", None)])
+def test_standalone_decoder_on_reference_fixtures(name, md5hex):
+    """The libFLAC-made files the reference's own tests hold decode on the GPU to the MD5 in their
+    STREAMINFO (sine.flac: the MD5 tests/format.rs checks) and to the oracle decoder's samples."""
+    from flac_codec_amd.gpu import decode_stream
+
+    blob = open(os.path.join(REFDATA, name), "rb").read()
+    pcm, info = decode_stream(blob)
+    assert info.bad_frames == 0 and info.bad_crc16 == 0
+    assert info.md5_status == 1, f"{name}: decoded MD5 {bytes(info.decoded_md5).hex()} != STREAMINFO {bytes(info.md5).hex()}"
+    if md5hex:
+        assert bytes(info.decoded_md5).hex() == md5hex
+    rc, ref, oinfo = orc.decode_stream(blob)
+    assert rc == 0 and oinfo.md5_ok == 1
+    assert info.frames == oinfo.frames and info.decoded_samples == (info.total_samples or info.decoded_samples)
+    assert np.array_equal(pcm, ref)
+
+
+def test_standalone_decoder_on_own_streams_and_corruption():
+    from flac_codec_amd.encode import FlacSampleWriter, Options
+    from flac_codec_amd.gpu import decode_stream
+
+    for (ch, bps, n, opts) in [(2, 24, 4096 * 9 + 123, Options.best()), (2, 16, 1152 * 20 + 7, Options.fast()),
+                               (6, 20, 4096 * 3, Options.default()), (1, 8, 5000, Options.best().block_size(1000)),
+                               (2, 24, 4096 * 4, Options.best().max_lpc_order(32))]:
+        pcm = synth_fast(4000 + ch + bps, ch, bps, n)
+        w = FlacSampleWriter(None, opts, 48000, bps, ch, pcm.size)
+        w.write(pcm)
+        w.finalize()
+        data = w.getvalue()
+        w.close()
+        out, info = decode_stream(data)
+        assert info.md5_status == 1 and info.bad_frames == 0 and np.array_equal(out, pcm)
+        # a flipped bit inside a frame is caught (CRC-16 chain breaks -> the scan stops there)
+        bad = bytearray(data)
+        bad[len(bad) - len(bad) // 8] ^= 0x10   # inside the frames (the first half may be PADDING)
+        _, binfo = decode_stream(bytes(bad))
+        assert binfo.md5_status != 1 or binfo.bad_frames or binfo.frames != info.frames
