@@ -73,6 +73,7 @@ struct flacgpu_ctx {
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
     uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate); = d_stats + 4
+    int32_t *d_big = nullptr;       // blocks > LDS_BLOCK_LIMIT: per-workgroup arrays of the generic kernels
     int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
     uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
@@ -206,8 +207,16 @@ size_t pack_lds_bytes(uint32_t block_size) { return (size_t)pack_sb_words(block_
 
 // K0 for frames [f0, f0 + fcount): split the channels into planar rows and OR every candidate's
 // samples.  Returns true when the orbits are already accumulated.
+constexpr uint32_t kGridY = 65535;   // frames per launch of the kernels that index frames with blockIdx.y
+
 bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames, uint32_t last_len,
                uint32_t f0, uint32_t fcount, hipStream_t st) {
+    if (fcount > kGridY) {   // batches of more than 65535 frames: several launches
+        bool r = false;
+        for (uint32_t f = f0; f < f0 + fcount; f += kGridY)
+            r = launch_k0(c, d_pcm, layout, n_frames, last_len, f, std::min(kGridY, f0 + fcount - f), st);
+        return r;
+    }
     const uint32_t B = c->opts.block_size;
     const dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), fcount);  // 8 samples per lane
     if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
@@ -250,12 +259,23 @@ void launch_k0_packed_c(flacgpu_ctx *c, uint32_t bytes, const dim3 &grid, uint32
 }
 void launch_k0_packed(flacgpu_ctx *c, uint32_t bytes, uint32_t n_frames, uint32_t last_len, hipStream_t st) {
     const uint32_t B = c->opts.block_size;
-    const dim3 grid(std::max<uint32_t>(1u, (B / 4 + WG - 1) / WG), n_frames);   // 4 PCM frames per lane
-    switch (c->channels) {
-#define X(C) case C: launch_k0_packed_c<C>(c, bytes, grid, n_frames, last_len, 0, st); break;
-        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += kGridY) {
+        const dim3 grid(std::max<uint32_t>(1u, (B / 4 + WG - 1) / WG), std::min(kGridY, n_frames - f0));   // 4 PCM frames per lane
+        switch (c->channels) {
+#define X(C) case C: launch_k0_packed_c<C>(c, bytes, grid, n_frames, last_len, f0, st); break;
+            X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 #undef X
-    default: break;
+        default: break;
+        }
+    }
+}
+void launch_orbits(const Params &p, uint32_t *orbits, hipStream_t st) {
+    for (uint32_t f = p.f0; f < p.f0 + p.fcount; f += kGridY) {
+        Params r = p;
+        r.f0 = f;
+        r.fcount = std::min(kGridY, p.f0 + p.fcount - f);
+        hipLaunchKernelGGL(k_orbits, dim3(std::max<uint32_t>(1u, (p.block_size + WG * 8 - 1) / (WG * 8)), r.fcount),
+                           dim3(WG), 0, st, r, orbits);
     }
 }
 
@@ -290,11 +310,11 @@ static int set_kernel_attributes_once(int device) {
     static bool done[64] = {};
     std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= 64 || done[device]) return FLACGPU_OK;
-    const size_t B = FLACGPU_MAX_BLOCK_SIZE;
+    const size_t B = LDS_BLOCK_LIMIT;
     const int dyn = (int)((2 * B + B / 16 + 16) * sizeof(int32_t));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fixed, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_fir, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fixed_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_fir_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_emit_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * sizeof(int32_t))));
     HIP_TRY(pack_set_attributes(pack_lds_bytes((uint32_t)B)));
     done[device] = true;
     return FLACGPU_OK;
@@ -309,13 +329,9 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     // Options validation, encode.rs:1418-1455; stream validation, :495, :1904
     if (o->block_size < 16 || o->block_size > 65535 || o->max_lpc_order > 32 ||
         o->max_partition_order > 15 || bps < 1 || bps > 32 || channels < 1 || channels > 8 ||
-        max_frames == 0 || max_frames > 65535) {  // frames index gridDim.y of K0
+        max_frames == 0 || max_frames > (1u << 24)) {
         g_last_error = "invalid option / stream parameter";
         return FLACGPU_ERR_INVALID_ARG;
-    }
-    if (o->block_size > FLACGPU_MAX_BLOCK_SIZE) {
-        g_last_error = "block_size > FLACGPU_MAX_BLOCK_SIZE is not supported by the LDS-resident kernels";
-        return FLACGPU_ERR_UNSUPPORTED;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -374,6 +390,7 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
     ALLOC(c->d_frame_off, F + 1);
+    if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
 #undef ALLOC
     // non-blocking: contexts must not synchronise with each other through the legacy null stream
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -412,7 +429,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off);
-    (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify);
+    (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify); (void)hipFree(c->d_big);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -461,6 +478,8 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.frame_plan = c->d_fplan;
     p.residuals = c->d_resid;
     p.stats = c->d_stats;
+    p.big_scratch = c->d_big;
+    p.big_stride = big_scratch_ints(B);
 
 }
 
@@ -548,8 +567,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, 0, n_frames, st);
     }
     if (!have_orbits)
-        hipLaunchKernelGGL(k_orbits, dim3(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), n_frames), dim3(WG), 0, st, p,
-                           c->d_orbits);
+        launch_orbits(p, c->d_orbits, st);
     const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
     if (c->stereo4 && !p.exhaustive) {
         begin(1);
@@ -581,7 +599,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     }
     if (pg.fcount) {
         begin(2);
-        hipLaunchKernelGGL(k_fixed, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, sf, pg);
+        if (B > LDS_BLOCK_LIMIT) hipLaunchKernelGGL(k_fixed_t<true>, dim3(pg.fcount * c->ncand), dim3(WG), 0, sf, pg);
+        else hipLaunchKernelGGL(k_fixed_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, sf, pg);
     }
     if (fork) HIP_TRY(hipEventRecord(c->ev_join, sf));
     if (lpc) {
@@ -595,7 +614,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         if (pg.fcount) {
             begin(5);
-            hipLaunchKernelGGL(k_fir, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
+            if (B > LDS_BLOCK_LIMIT) hipLaunchKernelGGL(k_fir_t<true>, dim3(pg.fcount * c->ncand), dim3(WG), 0, st, pg);
+            else hipLaunchKernelGGL(k_fir_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
         }
     }
     if (w64 && pf.fcount) {
@@ -630,8 +650,11 @@ static int ensure_residual_rows(flacgpu_ctx *c) {
     if (c->resid_valid) return FLACGPU_OK;
     if (int rc = ctx_sync(c)) return rc;
     const Params &p = c->last_params;
-    hipLaunchKernelGGL(k_emit, dim3(p.n_frames * p.channels), dim3(WG),
-                       (size_t)p.block_size * sizeof(int32_t), ctx_stream(c), p);
+    if (p.block_size > LDS_BLOCK_LIMIT)
+        hipLaunchKernelGGL(k_emit_t<true>, dim3(p.n_frames * p.channels), dim3(WG), 0, ctx_stream(c), p);
+    else
+        hipLaunchKernelGGL(k_emit_t<false>, dim3(p.n_frames * p.channels), dim3(WG),
+                           (size_t)p.block_size * sizeof(int32_t), ctx_stream(c), p);
     HIP_TRY(hipGetLastError());
     if (int rc = ctx_sync(c)) return rc;
     c->resid_valid = true;
@@ -732,8 +755,11 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     if (pf.fcount) launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
     if (pg.fcount) {
         if (!c->resid_valid) {  // residual rows of these frames
-            hipLaunchKernelGGL(k_emit, dim3(pg.fcount * p.channels), dim3(WG),
-                               (size_t)p.block_size * sizeof(int32_t), st, pg);
+            if (p.block_size > LDS_BLOCK_LIMIT)
+                hipLaunchKernelGGL(k_emit_t<true>, dim3(pg.fcount * p.channels), dim3(WG), 0, st, pg);
+            else
+                hipLaunchKernelGGL(k_emit_t<false>, dim3(pg.fcount * p.channels), dim3(WG),
+                                   (size_t)p.block_size * sizeof(int32_t), st, pg);
         }
         launch_pack(pg, q, pg.fcount * p.channels, pack_lds_bytes(p.block_size), st);
     }
@@ -830,10 +856,9 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         r.f0 = half ? h : 0;
         r.fcount = half ? n_frames - h : h;
         const uint32_t ncb = r.fcount * c->ncand;
-        const dim3 g0(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), r.fcount);
         bool have_orbits = false;
         if (!planar_direct) have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, r.f0, r.fcount, st);
-        if (!have_orbits) hipLaunchKernelGGL(k_orbits, g0, dim3(WG), 0, st, r, c->d_orbits);
+        if (!have_orbits) launch_orbits(r, c->d_orbits, st);
         if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats, dim3(r.fcount), dim3(WG), 0, st, r);
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits);
         if (lpc) {

@@ -1296,10 +1296,7 @@ int flacenc_stream_writer_write(flacenc_stream_writer *w, uint32_t rate, uint32_
         return FLACENC_ERR_NON_SUBSET_BITS_PER_SAMPLE;
     uint32_t cap = 16;
     while (cap < n) cap <<= 1;
-    if (cap > FLACGPU_MAX_BLOCK_SIZE) {
-        g_err = "block larger than FLACGPU_MAX_BLOCK_SIZE";
-        return FLACENC_ERR_UNSUPPORTED;
-    }
+    cap = std::min<uint32_t>(cap, FLACGPU_MAX_BLOCK_SIZE);
     flacenc_stream_writer::Key key{bps, channels, cap};
     flacgpu_ctx *ctx = nullptr;
     auto it = w->ctxs.find(key);

@@ -75,9 +75,17 @@ struct Params {
     flacgpu_frame_plan *frame_plan;
     int32_t *residuals;                            // [n_frames][channels][block_size]
     uint32_t *stats;                               // [4]
+    int32_t *big_scratch;                          // blocks > LDS_BLOCK_LIMIT: per-workgroup arrays in HBM
+    uint32_t big_stride;                           // ints per workgroup in big_scratch
 };
 
 
+// largest block the generic kernels keep whole in LDS (k_fixed / k_fir: two arrays of it); larger
+// blocks (up to 65535, encode.rs:1418-1423) use per-workgroup arrays in HBM instead
+constexpr uint32_t LDS_BLOCK_LIMIT = 16384;
+__host__ __device__ constexpr uint32_t big_scratch_ints(uint32_t block_size) {
+    return 2u * (block_size + block_size / 16u + 16u) + 64u;   // x[n] | r[n] with the RIDX padding
+}
 constexpr int AC_LD = 36;        // row stride of the ac buffer (max lag group count rounded up)
 constexpr uint32_t FN = 4096;    // the block length of every preset but `fast`
 

@@ -29,7 +29,8 @@ void launch_zero(const PackParams &q, uint32_t n_frames, hipStream_t st) {
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, n_frames);
 }
 void launch_pack(const Params &p, const PackParams &q, uint32_t blocks, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(WG), lds, st, p, q);
+    if (p.block_size > LDS_BLOCK_LIMIT) hipLaunchKernelGGL(k_pack_t<true>, dim3(blocks), dim3(WG), 0, st, p, q);
+    else hipLaunchKernelGGL(k_pack_t<false>, dim3(blocks), dim3(WG), lds, st, p, q);
 }
 void launch_crc(bool verify, const Params &p, const PackParams &q, uint32_t frames, uint32_t *verify_counts,
                 hipStream_t st) {
@@ -37,6 +38,6 @@ void launch_crc(bool verify, const Params &p, const PackParams &q, uint32_t fram
     else hipLaunchKernelGGL(k_crc<false>, dim3(frames), dim3(WG), 0, st, p, q, verify_counts);
 }
 hipError_t pack_set_attributes(size_t pack_lds) {
-    return hipFuncSetAttribute((const void *)k_pack, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds);
+    return hipFuncSetAttribute((const void *)k_pack_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds);
 }
 }  // namespace flacgpu_k

@@ -37,7 +37,8 @@ extern "C" {
 #define FLACGPU_MAX_CHANNELS 8
 #define FLACGPU_MAX_LPC_ORDER 32
 #define FLACGPU_MAX_PARTITIONS 64
-#define FLACGPU_MAX_BLOCK_SIZE 16384 /* LDS-resident block; larger blocks: FLACGPU_ERR_UNSUPPORTED */
+#define FLACGPU_MAX_BLOCK_SIZE 65535 /* every block size the reference accepts (encode.rs:1418-1423); blocks
+                                        above 16384 take kernels that keep their arrays in HBM, not LDS */
 
 enum {
     FLACGPU_OK = 0,
@@ -56,7 +57,7 @@ enum { FLACGPU_WINDOW_RECTANGLE = 0, FLACGPU_WINDOW_HANN = 1, FLACGPU_WINDOW_TUK
 /* Mirror of `EncoderOptions` (encode.rs:1701-1709) + Options::block_size (:1366).
  * use_rice2 is derived exactly like encode.rs:1965 (stream bits_per_sample > 16). */
 typedef struct {
-    uint32_t block_size;          /* 16..=FLACGPU_MAX_BLOCK_SIZE */
+    uint32_t block_size;          /* 16..=65535 */
     uint32_t max_partition_order; /* 0..=15 (effective order is capped at 6, see above) */
     uint32_t max_lpc_order;       /* 0 = None, else 1..=32 */
     uint8_t mid_side;
