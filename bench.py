@@ -408,7 +408,8 @@ def main():
 
     out = None
     if rank == 0:
-        analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties, "log2_edge": st.log2_edge,
+        analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties,
+                          "order_ties_resolved_on_host": st.order_ties_resolved, "log2_edge": st.log2_edge,
                           "candidates": (4 if C == 2 else C) * F}
         verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
                   "Msamples/s": round(F * BLOCK * C / (vms * 1e-3) / 1e6, 1)}

@@ -92,6 +92,7 @@ class GpuStats(C.Structure):
         ("lpc_failed", C.c_uint32),
         ("order_ties", C.c_uint32),
         ("log2_edge", C.c_uint32),
+        ("order_ties_resolved", C.c_uint32),
     ]
 
 

@@ -30,6 +30,7 @@
 //   N3    k_decode (decode.inc)  decode.rs:1388-1856 read_frame .. predict, one lane per subframe
 #include "kernels/types.h"
 #include "checksums.h"
+#include "lpc_host.h"
 
 #include <math.h>
 #include <stdint.h>
@@ -73,6 +74,14 @@ struct flacgpu_ctx {
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats = nullptr;
     uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate); = d_stats + 4
+    uint32_t *d_ties = nullptr;     // candidates whose LPC order estimates tie (k_lpc), [F * NC]
+    double tie_band = 1e-9, tie_perturb = 0.0;
+    bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
+    uint32_t ties_resolved = 0;     // candidates re-decided on the host for the last analysis
+    uint32_t last_n_fast = 0;       // frames of the last analysis that took the wave kernels
+    uint64_t last_first_frame = 0;  // arguments of the last frame assembly (re-run after a re-decision)
+    uint32_t last_rate = 0;
+    uint32_t *h_stats = nullptr;    // pinned copy of the 4 counters (asynchronous host path)
     int32_t *d_big = nullptr;       // blocks > LDS_BLOCK_LIMIT: per-workgroup arrays of the generic kernels
     int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
     uint32_t *d_verify = nullptr;   // [4] verify counters
@@ -391,6 +400,9 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
     ALLOC(c->d_frame_off, F + 1);
     if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
+    ALLOC(c->d_ties, F * NC);
+    if (const char *e = getenv("FLACGPU_TIE_BAND")) c->tie_band = atof(e);         // test knobs
+    if (const char *e = getenv("FLACGPU_TIE_PERTURB")) c->tie_perturb = atof(e);
 #undef ALLOC
     // non-blocking: contexts must not synchronise with each other through the legacy null stream
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -410,6 +422,7 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_bytes, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&c->h_off, sizeof(uint64_t) * (F + 1), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_stats, sizeof(uint32_t) * 4, hipHostMallocDefault));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     c->ev_ok = true;
     return FLACGPU_OK;
@@ -421,6 +434,8 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->h_off) (void)hipHostFree(c->h_off);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    (void)hipFree(c->d_ties);
     if (c->ev_sizes) (void)hipEventDestroy(c->ev_sizes);
     if (c->ev_bytes) (void)hipEventDestroy(c->ev_bytes);
     if (c->ev_null) (void)hipEventDestroy(c->ev_null);
@@ -480,6 +495,10 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.stats = c->d_stats;
     p.big_scratch = c->d_big;
     p.big_stride = big_scratch_ints(B);
+    p.tie_list = c->d_ties;
+    p.tie_cap = c->max_frames * c->ncand;
+    p.tie_band = c->tie_band;
+    p.tie_perturb = c->tie_perturb;
 
 }
 
@@ -624,6 +643,9 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     }
     begin(6);
     hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
+    c->last_n_fast = pf.fcount;
+    c->ties_checked = !lpc;
+    c->ties_resolved = 0;
     // the residual rows (k_emit) are produced lazily: flacgpu_fetch(residuals) / host packing
     // need them, the device-side packer recomputes residuals in registers instead
     c->resid_valid = false;
@@ -644,6 +666,78 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         }
     }
     return FLACGPU_OK;
+}
+
+static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate, hipStream_t st,
+                     hipEvent_t after_layout);
+
+// The candidates k_lpc listed (two best order estimates closer than the device's log() can be trusted
+// to separate) are re-decided here with the HOST's libm -- Levinson, order choice and quantisation
+// from the device's exact autocorrelation (host/lpc_host.cpp) --, their parameters replaced, and the
+// candidate stage, the assignment decision and (when done before) the frame assembly run again, so
+// that the output is what the reference produces with this host's libm (encode.rs:3656-3702).
+static int resolve_order_ties(flacgpu_ctx *c) {
+    if (c->ties_checked || c->last_frames == 0) return FLACGPU_OK;
+    if (int rc = ctx_sync(c)) return rc;
+    c->ties_checked = true;
+    uint32_t s[4];
+    if (int rc = copy_sync(c, s, c->d_stats, sizeof s, hipMemcpyDeviceToHost)) return rc;
+    const uint32_t cap = c->max_frames * c->ncand;
+    const uint32_t n_ties = std::min(s[1], cap);
+    if (n_ties == 0) return FLACGPU_OK;
+    static_assert(sizeof(flacenc::HostLpc) == sizeof(LpcParams), "same record on both sides");
+    std::vector<uint32_t> list(n_ties);
+    if (int rc = copy_sync(c, list.data(), c->d_ties, sizeof(uint32_t) * n_ties, hipMemcpyDeviceToHost)) return rc;
+    const Params p = c->last_params;
+    const size_t nc = (size_t)p.n_frames * p.ncand;
+    std::vector<double> ac;
+    std::vector<CandInfo> ci;
+    const bool bulk = n_ties > 32;
+    if (bulk) {
+        ac.resize(nc * AC_LD);
+        ci.resize(nc);
+        if (int rc = copy_sync(c, ac.data(), c->d_ac, sizeof(double) * ac.size(), hipMemcpyDeviceToHost)) return rc;
+        if (int rc = copy_sync(c, ci.data(), c->d_cinfo, sizeof(CandInfo) * nc, hipMemcpyDeviceToHost)) return rc;
+    }
+    hipStream_t st = ctx_stream(c);
+    for (uint32_t idx : list) {
+        if (idx >= nc) continue;
+        double row[AC_LD];
+        CandInfo info;
+        if (bulk) {
+            memcpy(row, ac.data() + (size_t)idx * AC_LD, sizeof row);
+            info = ci[idx];
+        } else {
+            if (int rc = copy_sync(c, row, c->d_ac + (size_t)idx * AC_LD, sizeof row, hipMemcpyDeviceToHost)) return rc;
+            if (int rc = copy_sync(c, &info, c->d_cinfo + idx, sizeof info, hipMemcpyDeviceToHost)) return rc;
+        }
+        const uint32_t frame = idx / p.ncand;
+        const uint32_t n = (frame + 1 == p.n_frames) ? p.last_len : p.block_size;
+        flacenc::HostLpc h;
+        flacenc::lpc_from_autocorr(row, p.max_lpc_order, n, info.bps, &h);
+        HIP_TRY(hipMemcpyAsync(c->d_lpc + idx, &h, sizeof h, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));   // `h` is a local
+    }
+    // candidate stage + assignment again (k_fixed's results are still in place)
+    const uint32_t B = p.block_size;
+    Params pf = p, pg = p;
+    pf.f0 = 0;
+    pf.fcount = c->last_n_fast;
+    pg.f0 = c->last_n_fast;
+    pg.fcount = p.n_frames - c->last_n_fast;
+    const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
+    if (pg.fcount) {
+        if (B > LDS_BLOCK_LIMIT) hipLaunchKernelGGL(k_fir_t<true>, dim3(pg.fcount * c->ncand), dim3(WG), 0, st, pg);
+        else hipLaunchKernelGGL(k_fir_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
+    }
+    if (pf.fcount) launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
+    hipLaunchKernelGGL(k_decide, dim3(p.n_frames), dim3(64), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    c->resid_valid = false;
+    c->ties_resolved = n_ties;
+    if (c->packed_valid)
+        if (int rc = pack_impl(c, c->last_first_frame, c->last_rate, st, nullptr)) return rc;
+    return ctx_sync(c);
 }
 
 static int ensure_residual_rows(flacgpu_ctx *c) {
@@ -668,6 +762,7 @@ int flacgpu_fetch(flacgpu_ctx *c, flacgpu_frame_plan *plans, flacgpu_subframe_pl
     const size_t F = c->last_frames;
     hipStream_t st = c->own_stream;
     if (int rc = ctx_sync(c)) return rc;
+    if (int rc = resolve_order_ties(c)) return rc;
     if (residuals)
         if (int rc = ensure_residual_rows(c)) return rc;
     if (plans) HIP_TRY(hipMemcpyAsync(plans, c->d_fplan, sizeof(*plans) * F, hipMemcpyDeviceToHost, st));
@@ -718,6 +813,8 @@ int flacgpu_pack_device(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sa
 
 static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sample_rate, hipStream_t st,
                      hipEvent_t after_layout) {
+    c->last_first_frame = first_frame_number;
+    c->last_rate = sample_rate;
     const Params &p = c->last_params;
     PackParams q;
     q.first_frame_number = first_frame_number;
@@ -882,6 +979,11 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     c->last_params = p;
     c->last_stream = st0;
     c->packed_valid = true;
+    c->last_n_fast = n_frames;
+    c->ties_checked = !lpc;
+    c->ties_resolved = 0;
+    c->last_first_frame = first_frame_number;
+    c->last_rate = sample_rate;
     return FLACGPU_OK;
 }
 
@@ -894,6 +996,7 @@ int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *off
     CTX_GUARD(c);
     const size_t F = c->last_frames;
     if (int rc = ctx_sync(c)) return rc;
+    if (int rc = resolve_order_ties(c)) return rc;
     std::vector<uint64_t> off;
     uint64_t *offp = offsets;
     if (!offp) {
@@ -1245,6 +1348,7 @@ int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t 
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_layout, 0));
     HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
                            hipMemcpyDeviceToHost, c->aux_stream));
+    HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->aux_stream));
     HIP_TRY(hipEventRecord(c->ev_sizes, c->aux_stream));
     c->sizes_pending = true;
     c->bytes_pending = false;
@@ -1258,6 +1362,16 @@ int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *tot
     }
     CTX_GUARD(c);
     HIP_TRY(hipEventSynchronize(c->ev_sizes));
+    if (!c->ties_checked) {
+        if (c->h_stats[1] == 0) {
+            c->ties_checked = true;   // the common case: nothing to re-decide, nothing to wait for
+        } else {                      // order ties: host re-decision, then the sizes again
+            if (int rc = resolve_order_ties(c)) return rc;
+            if (int rc = copy_sync(c, c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)c->last_frames + 1),
+                                   hipMemcpyDeviceToHost))
+                return rc;
+        }
+    }
     if (offsets) *offsets = c->h_off;
     if (total) *total = c->h_off[c->last_frames];
     return FLACGPU_OK;
@@ -1353,6 +1467,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
+    if (int rc = resolve_order_ties(c)) return rc;
     hipStream_t st = c->own_stream;
     Params p = c->last_params;
     const size_t F = c->max_frames, C = c->channels;
@@ -1435,6 +1550,7 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     out->lpc_failed = s[0];
     out->order_ties = s[1];
     out->log2_edge = s[2];
+    out->order_ties_resolved = c->ties_resolved;
     return FLACGPU_OK;
 }
 

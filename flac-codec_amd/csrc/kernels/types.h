@@ -77,6 +77,12 @@ struct Params {
     uint32_t *stats;                               // [4]
     int32_t *big_scratch;                          // blocks > LDS_BLOCK_LIMIT: per-workgroup arrays in HBM
     uint32_t big_stride;                           // ints per workgroup in big_scratch
+    // LPC order choice: candidates whose two best estimates lie within tie_band (relative) are listed
+    // (stats[1] counts them) and re-decided on the host with its libm; tie_perturb is a TEST knob
+    // (0 in production) that skews the device's estimates inside the band
+    uint32_t *tie_list;
+    uint32_t tie_cap;
+    double tie_band, tie_perturb;
 };
 
 

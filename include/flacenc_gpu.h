@@ -114,10 +114,14 @@ typedef struct {
     uint32_t frames;
     uint32_t lpc_failed;        /* candidates whose LPC path errored (fell back to FIXED) */
     uint32_t order_ties;        /* candidates whose two best LPC-order estimates were within
-                                   1e-9 relative (libm-sensitive; 0 => order choice is
-                                   independent of the last-ulp behaviour of log()) */
+                                   1e-9 relative: inside that band the device's log() is not
+                                   trusted to pick like the host libm the reference uses; they are
+                                   re-decided on the host (see order_ties_resolved) */
     uint32_t log2_edge;         /* quantise calls where max|c| sat in the libm-sensitive band
                                    just below a power of two (handled by the host table) */
+    uint32_t order_ties_resolved; /* of order_ties: candidates whose LPC parameters were recomputed on
+                                   the host with its libm (encode.rs:3656-3702) before the results
+                                   were handed out; every fetch / verify entry point does this */
 } flacgpu_stats;
 
 typedef struct flacgpu_ctx flacgpu_ctx;

@@ -155,3 +155,53 @@ def test_mfma_autocorr_experiment_is_close_but_not_the_product_path():
     plans1, subs1, res1 = an.fetch(16)
     assert bytes(subs0) == bytes(subs1) and np.array_equal(res0, res1)
     an.close()
+
+
+def test_order_ties_are_redecided_on_the_host(monkeypatch):
+    """LPC order choice near a tie (encode.rs:3656-3702): candidates whose two best estimates lie
+    inside the band are re-decided on the host with its libm.  The band is widened to 1e-3 and the
+    device's estimates are skewed by 1e-4 (test knobs of the context), so that the device alone picks
+    other orders for many candidates: the output must still be the oracle's, because every skewed
+    decision falls inside the band and is redone on the host."""
+    import os
+    import _oracle as orc
+    from _compare import orc_options_for, planar_frames
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    # a first-order autoregressive signal: order 1 is the reference's choice, the higher orders lose
+    # only by their header bits (a few 1e-4 of the estimate), and LPC beats FIXED either way
+    from scipy.signal import lfilter
+
+    rng = np.random.Generator(np.random.PCG64(9))
+    chans = [np.clip(np.rint(lfilter([1.0], [1.0, -0.9], rng.uniform(-1500, 1500, size=4096 * 24))), -32768, 32767)
+             for _ in range(2)]
+    pcm = np.stack(chans, axis=1).astype(np.int32).reshape(-1)
+    frames = planar_frames(pcm, 2, 4096)
+    oopts = orc_options_for(4096, 6, 12, True, True)
+
+    def encode(env):
+        for k in ("FLACGPU_TIE_BAND", "FLACGPU_TIE_PERTURB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 16, 2, max_frames=len(frames))
+        data, off = an.encode_frames(pcm, len(frames), 4096, 0, 48000)
+        st = an.stats()
+        an.close()
+        return data, off, st
+
+    # skewed device estimates, band too narrow to notice: the output differs from the oracle somewhere
+    skew, off_s, st_s = encode({"FLACGPU_TIE_BAND": "1e-30", "FLACGPU_TIE_PERTURB": "-1e-3"})
+    # skewed device estimates inside a wide band: everything that could differ is redone on the host
+    data, off, st = encode({"FLACGPU_TIE_BAND": "1e-2", "FLACGPU_TIE_PERTURB": "-1e-3"})
+    assert st.order_ties > 0 and st.order_ties_resolved == st.order_ties
+    differs = 0
+    for f, planar in enumerate(frames):
+        rc, fb, _ = orc.encode_frame(oopts, 48000, 16, planar, frame_number=f)
+        assert rc == 0
+        assert data[off[f]:off[f + 1]] == fb, f"frame {f}: host re-decision did not restore the oracle's bytes"
+        differs += skew[off_s[f]:off_s[f + 1]] != fb
+    assert differs > 0, "the skew changed nothing: the test does not exercise the re-decision"
+    # production settings: nothing flagged on this input, same bytes
+    plain, off_p, st_p = encode({})
+    assert st_p.order_ties == 0 and plain == data
