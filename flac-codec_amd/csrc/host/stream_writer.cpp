@@ -496,6 +496,7 @@ struct flacenc_writer {
     std::vector<uint8_t> outbuf;  // frames fetched from the device
     flacenc_stats stats{};
 
+    bool header_only = false;
     CtxKey gpu_key{};
     ~flacenc_writer() {
         for (auto &f : inflight) (void)flacgpu_wait(f.lane->gpu);   // nothing may still write into a pooled lane
@@ -577,6 +578,7 @@ struct flacenc_writer {
         std::vector<uint8_t> hdr = build_metadata(si, meta);
         metadata_len = hdr.size();
         if (int e = sink.write(hdr.data(), hdr.size())) return e;
+        if (header_only) return 0;   // flacenc_stream_header: bookkeeping without an analysis lane
         batch_frames = o.batch_frames ? o.batch_frames : 256;
         unsigned hw = std::thread::hardware_concurrency();
         pack_threads = o.pack_threads ? o.pack_threads : std::max(1u, std::min(hw, 16u));
@@ -962,7 +964,7 @@ struct flacenc_writer {
             if (samples_written == 0) return FLACENC_ERR_NO_SAMPLES;
             si.total_samples = samples_written;
         }
-        md5.digest(si.md5);
+        if (!header_only) md5.digest(si.md5);
         std::vector<uint8_t> hdr = build_metadata(si, meta);
         if (hdr.size() != metadata_len) {
             g_err = "internal: metadata size changed at finalize";
@@ -1205,6 +1207,43 @@ int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n
     for (auto &th : pool) th.join();
     for (size_t i = 0; i < n_jobs; i++)
         if (jobs[i].status) return jobs[i].status;
+    return 0;
+}
+
+// The bytes in front of the first frame (fLaC marker + STREAMINFO + SEEKTABLE + VORBIS_COMMENT +
+// PADDING) exactly as a writer that had produced frames of these sizes would leave them at finalize
+// (Encoder::new + encode's seek points + finalize_inner, encode.rs:1882-1980, 1999-2003, 2024-2110):
+// what the owner of a stream whose frame ranges were encoded elsewhere (other GPUs) needs.
+int flacenc_stream_header(const flacenc_options *opts, uint32_t sample_rate, uint32_t bits_per_sample,
+                          uint32_t channels, uint64_t total_pcm_frames, const uint8_t md5[16], uint64_t n_frames,
+                          const uint32_t *frame_sizes, uint32_t last_frame_len, uint8_t *out, size_t cap,
+                          size_t *len) {
+    if (!opts || !md5 || !frame_sizes || !len || n_frames == 0 || last_frame_len == 0 ||
+        last_frame_len > opts->block_size)
+        return FLACENC_ERR_INVALID_ARG;
+    if (bits_per_sample < 1 || bits_per_sample > 32) return FLACENC_ERR_INVALID_BITS_PER_SAMPLE;
+    flacenc_writer w;
+    w.header_only = true;
+    if (int rc = w.init(*opts, sample_rate, bits_per_sample, channels, true, total_pcm_frames, nullptr)) return rc;
+    const uint32_t B = opts->block_size;
+    for (uint64_t f = 0; f < n_frames; f++) {
+        const uint32_t n = (f + 1 == n_frames) ? last_frame_len : B;
+        w.seekpoints.push_back({w.samples_written, w.byte_count, static_cast<uint16_t>(n), true});
+        w.samples_written += n;
+        const uint32_t size = frame_sizes[f];
+        if (size != 0 && size < kMaxFrameSize) {
+            w.si.min_frame = w.si.min_frame ? std::min(w.si.min_frame, size) : size;
+            w.si.max_frame = std::max(w.si.max_frame, size);
+        }
+        w.byte_count += size;
+    }
+    w.frame_number = n_frames;
+    std::memcpy(w.si.md5, md5, 16);
+    w.finalized = true;
+    if (int rc = w.finalize_encoder()) return rc;
+    *len = w.metadata_len;
+    if (!out || cap < w.metadata_len) return FLACENC_ERR_INVALID_ARG;
+    std::memcpy(out, w.sink.mem.data(), w.metadata_len);
     return 0;
 }
 

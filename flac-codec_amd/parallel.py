@@ -9,6 +9,7 @@ per rank (RCCL over xGMI when the backend is "nccl") carries all of it.  The str
 serial chain over the PCM and stays with whoever owns the input (encode.rs:571, 2100).
 """
 import ctypes as C
+import ctypes as C_
 
 from . import _lib
 
@@ -63,3 +64,106 @@ def merge_counters(per_rank):
 def gather_shard_counters(analyzer, n_frames, dist=None):
     per_rank = all_gather_counters(local_counters(analyzer, n_frames), dist)
     return merge_counters(per_rank)
+
+
+def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, dist=None, device=-1,
+                          batch_frames=1024):
+    """ONE stream encoded by every rank of `dist` together.
+
+    The stream's blocks are cut into contiguous frame ranges (`shard_range`), each rank encodes its
+    range on its GPU with the frame numbers the whole stream gives them; what crosses ranks is
+      1. one all-gather of {frames, bytes, min_frame, max_frame} per rank (`merge_counters`:
+         shard byte offsets, totals, STREAMINFO min/max frame size; encode.rs:2414-2436),
+      2. one gather of the per-frame sizes (4 bytes a frame) to rank 0, from which the owner rebuilds
+         the seek points exactly as the single writer would (encode.rs:1999-2003),
+      3. the gather of the finished frame bytes to rank 0 (the only data movement; compressed).
+    Rank 0 owns the input: it computes the stream MD5 (a serial chain over the whole PCM that cannot be
+    merged from partial states, encode.rs:571, 2100), builds the metadata with flacenc_stream_header
+    and returns the .flac bytes -- identical to what one FlacSampleWriter produces.  Other ranks
+    return None.  `pcm`: interleaved int32 samples of the WHOLE stream (every rank reads its own
+    range of it); `options`: flac_codec_amd.encode.Options.
+    """
+    import hashlib
+
+    import numpy as np
+
+    from . import encode as E
+    from .gpu import GpuAnalyzer
+
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    co = options._c_options()
+    B, C = co.block_size, channels
+    total_pcm = pcm.size // C
+    if pcm.size % C or total_pcm == 0:
+        raise ValueError("samples not divisible by channels")
+    n_frames = (total_pcm + B - 1) // B
+    last_len = total_pcm - (n_frames - 1) * B
+    lo, hi = shard_range(n_frames, world, rank)
+    an = None
+    chunks, sizes = [], []
+    if hi > lo:
+        an = GpuAnalyzer(B, co.max_partition_order, co.max_lpc_order, co.mid_side, co.exhaustive_channel_correlation,
+                         co.window_kind, co.window_param, bits_per_sample, C, max_frames=min(batch_frames, hi - lo),
+                         device=device)
+        f = lo
+        while f < hi:
+            take = min(batch_frames, hi - f)
+            ll = last_len if f + take == n_frames else B
+            a, b = f * B * C, ((f + take - 1) * B + ll) * C
+            data, off = an.encode_frames(pcm[a:b], take, ll, f, sample_rate)
+            chunks.append(data)
+            sizes.extend(off[i + 1] - off[i] for i in range(take))
+            f += take
+        an.close()
+    mine = b"".join(chunks)
+    local = [hi - lo, len(mine), min(sizes) if sizes else 0, max(sizes) if sizes else 0]
+    per_rank = all_gather_counters(local, dist)
+    merged = merge_counters([c for c in per_rank if c[0]] or per_rank)
+    if world > 1:
+        import torch
+
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        max_frames = max(c[0] for c in per_rank)
+        max_bytes = max(c[1] for c in per_rank)
+        tsz = torch.zeros(max_frames, dtype=torch.int64, device=dev)
+        tsz[: len(sizes)] = torch.tensor(sizes, dtype=torch.int64)
+        tby = torch.zeros(max_bytes, dtype=torch.uint8, device=dev)
+        if mine:
+            tby[: len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        gsz = [torch.zeros_like(tsz) for _ in range(world)] if rank == 0 else None
+        gby = [torch.zeros_like(tby) for _ in range(world)] if rank == 0 else None
+        dist.gather(tsz, gsz, dst=0)
+        dist.gather(tby, gby, dst=0)
+        if rank != 0:
+            return None
+        all_sizes, body = [], []
+        for r, c in enumerate(per_rank):
+            all_sizes.extend(int(v) for v in gsz[r][: c[0]].tolist())
+            body.append(bytes(gby[r][: c[1]].cpu().numpy().tobytes()))
+        body = b"".join(body)
+    else:
+        all_sizes, body = sizes, mine
+    assert len(all_sizes) == n_frames and sum(all_sizes) == len(body) == merged["total_bytes"]
+    # the owner: MD5 over the little-endian ceil(bps/8)-byte samples of the whole stream
+    width = (bits_per_sample + 7) // 8
+    le = np.ascontiguousarray(pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width])
+    md5 = hashlib.md5(le.tobytes()).digest()
+    L = E._stream_lib()
+    L.flacenc_stream_header.argtypes = [C_.POINTER(E._COptions), C_.c_uint32, C_.c_uint32, C_.c_uint32, C_.c_uint64,
+                                        C_.c_char_p, C_.c_uint64, C_.POINTER(C_.c_uint32), C_.c_uint32, C_.c_void_p,
+                                        C_.c_size_t, C_.POINTER(C_.c_size_t)]
+    fs = (C_.c_uint32 * n_frames)(*all_sizes)
+    ln = C_.c_size_t(0)
+    cap = 1 << 20
+    buf = (C_.c_uint8 * cap)()
+    rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs, last_len,
+                                 buf, cap, C_.byref(ln))
+    if rc and ln.value > cap:
+        cap = ln.value
+        buf = (C_.c_uint8 * cap)()
+        rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs,
+                                     last_len, buf, cap, C_.byref(ln))
+    E._check(rc)
+    return bytes(buf[: ln.value]) + body

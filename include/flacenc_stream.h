@@ -201,6 +201,16 @@ int flacenc_pack_frames(uint32_t sample_rate, uint32_t bits_per_sample, uint32_t
                         const int32_t *residual_rows, uint32_t threads, uint8_t *out, size_t cap,
                         uint64_t *offsets);
 
+/* Everything in front of the first frame (fLaC + STREAMINFO + SEEKTABLE + VORBIS_COMMENT + PADDING)
+ * exactly as a writer that had emitted frames of these sizes leaves it at finalize: for the owner of a
+ * stream whose contiguous frame ranges were encoded on several GPUs (encode.rs:1999-2003
+ * seek points, 2414-2436 min/max frame size, 2024-2110 finalize).  `md5`: of the whole PCM, computed by
+ * the owner.  *len receives the size; FLACENC_ERR_INVALID_ARG when `cap` is too small. */
+int flacenc_stream_header(const flacenc_options *opts, uint32_t sample_rate, uint32_t bits_per_sample,
+                          uint32_t channels, uint64_t total_pcm_frames, const uint8_t md5[16], uint64_t n_frames,
+                          const uint32_t *frame_sizes, uint32_t last_frame_len, uint8_t *out, size_t cap,
+                          size_t *len);
+
 /* The 34-byte STREAMINFO body exactly as the writers serialise it (metadata/mod.rs:1599-1630). */
 int flacenc_streaminfo_bytes(uint32_t min_block, uint32_t max_block, uint32_t min_frame, uint32_t max_frame,
                              uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample,
