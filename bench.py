@@ -282,10 +282,16 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run before the warm-up until this much wall time has passed "
                          "(the clocks of an idle GPU take longer to ramp than a few batches)")
+    ap.add_argument("--experiment", choices=("mfma_autocorr",), default=None,
+                    help="mfma_autocorr: the f64-MFMA autocorrelation (re-associated sums, NOT bit-exact) in place "
+                         "of the exact kernel; the line is labelled and frames that differ from the oracle are "
+                         "counted instead of failing the run")
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="steps of the additional long timed loop reported as `sustained`")
     args = ap.parse_args()
 
+    if args.experiment == "mfma_autocorr":
+        os.environ["FLACGPU_EXPERIMENT_MFMA_AC"] = "1"   # read by the library when it first dispatches
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -384,10 +390,14 @@ def main():
     oopts = orc_options_for(BLOCK, MAX_PO, MAX_LPC, True, True)
     check = min(DISTINCT, F)
     ok = 1
+    frames_differ = 0
     for f in range(check):
         planar = np.ascontiguousarray(pcm[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
         rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
         if rc != 0 or data[off[f]:off[f + 1]] != fb:
+            frames_differ += 1
+            if args.experiment:
+                continue
             sys.stderr.write(f"rank {rank}: frame {f} differs from the oracle\n")
             ok = 0
             break
@@ -535,7 +545,8 @@ def main():
             "device_verify": verify,
             "compression_ratio": round(compressed_bytes / (F * BLOCK * C * ((BPS + 7) // 8)), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
-            "parity": {"frames_byte_identical_to_oracle_per_rank": check, "distinct_frames_in_batch": check,
+            "experiment": args.experiment,
+            "parity": {"frames_byte_identical_to_oracle_per_rank": check - frames_differ, "distinct_frames_in_batch": check,
                        "frames_round_tripped_on_device_per_rank": F, "ranks_checked": world},
             "analysis_stats": analysis_stats,
             "shard_counters": counters,

@@ -82,6 +82,15 @@ void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_
 namespace flacgpu_k {
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st) {
+    // EXPERIMENT switch (bench.py --experiment mfma_autocorr): the re-associating f64-MFMA kernel in
+    // place of the exact one, to measure what a whole step costs with the autocorrelation off the
+    // VALU pipe.  NOT bit-exact; never set in production.
+    static const bool mfma = getenv("FLACGPU_EXPERIMENT_MFMA_AC") != nullptr;
+    if (mfma && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 && frame0 == 0 && nframes == p.n_frames &&
+        n == p.block_size) {
+        hipLaunchKernelGGL(k_autocorr_mfma, dim3((nframes * p.ncand + 3) / 4), dim3(WG), 0, st, p, n, win, p.ac);
+        return;
+    }
     if (try_autocorr3(p, frame0, nframes, n, win, st)) return;
     switch (H) {
     case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
