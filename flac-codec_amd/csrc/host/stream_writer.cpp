@@ -577,6 +577,8 @@ struct flacenc_writer {
         }
         std::vector<uint8_t> hdr = build_metadata(si, meta);
         metadata_len = hdr.size();
+        if (sink.memory && !sink.fixed && has_total && !header_only)   // one allocation instead of doublings
+            sink.mem.reserve(hdr.size() + static_cast<size_t>(total_pcm_frames) * channels * bytes_per_sample * 3 / 4);
         if (int e = sink.write(hdr.data(), hdr.size())) return e;
         if (header_only) return 0;   // flacenc_stream_header: bookkeeping without an analysis lane
         batch_frames = o.batch_frames ? o.batch_frames : 256;
