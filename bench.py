@@ -127,15 +127,21 @@ def cpu_baseline(orc, cfg, pcm, frames_total):
     fn = max(64, min(frames_total, int(4096 * 8192 / per_frame)))
     ncores = os.cpu_count() or 1
     v1, n1 = run(f1, 1)
+    fj_threads = 4 if C <= 2 else min(16, 2 * C)
+    vf, nf = run(f1, -fj_threads)
     v4, n4 = run(fn, 4)
     va, na = run(fn, ncores)
     return {"value": round(v1, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"first {n1} frames of the bench batch, full encode to an in-memory .flac "
                       f"(MD5 + analysis + bit-pack + CRC), 1 thread, median of 5 after 1 warm-up",
+            "reference_fork_join": {"value": round(vf, 3), "cores": fj_threads, "frames": nf,
+                                    "note": "the reference's own task structure (encode.rs:2690-2745, 2906-2928, "
+                                            "3964-4010): frames strictly sequential, per frame L || R then M || S, "
+                                            "each subframe FIXED || LPC (<= 4 concurrent tasks for stereo, <= 16 for "
+                                            "8 channels), on a small work-helping pool"},
             "four_threads": {"value": round(v4, 3), "cores": 4, "frames": n4,
-                             "note": "frame-parallel restatement on 4 threads: an upper bound of the "
-                                     "reference's per-frame fork-join (at most 4 concurrent tasks per "
-                                     "stereo frame, frames sequential; encode.rs:2690-2745, 2906-2928)"},
+                             "note": "frame-parallel restatement on 4 threads (not what the reference does): an "
+                                     "upper bound of what its fork-join can reach with 4 cores"},
             "all_cores_frame_parallel": {"value": round(va, 3), "cores": ncores, "frames": na,
                                          "note": "not something the reference does"}}
 

@@ -540,6 +540,116 @@ typedef struct {
     chan_cache left, right, avg, diff;
 } enc_caches;
 
+/* ------------------------------------------------------------------ */
+/* join / try_join / vec_map, encode.rs:3964-4010: the reference forks   */
+/* at most channel-level tasks per frame with rayon (L || R, then        */
+/* M || S, each subframe FIXED || LPC; frames stay sequential).  A small  */
+/* work-helping pool restates that task structure for the timed CPU       */
+/* baseline (threads < 0 in orc_encode_stream: |threads| threads); the    */
+/* bytes are the same either way.                                         */
+/* ------------------------------------------------------------------ */
+typedef struct fj_task {
+    void (*fn)(void *);
+    void *arg;
+    volatile int done;
+} fj_task;
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    fj_task *q[64];
+    int nq, stop, nworkers;
+    pthread_t th[16];
+} g_fj = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, {0}};
+static volatile int g_fj_on = 0;
+
+static inline void fj_pause(void) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+static fj_task *fj_pop_locked(void) { return g_fj.nq ? g_fj.q[--g_fj.nq] : NULL; }
+static void *fj_worker(void *unused) {
+    (void)unused;
+    pthread_mutex_lock(&g_fj.mu);
+    for (;;) {
+        fj_task *t = fj_pop_locked();
+        if (!t) {
+            if (g_fj.stop) break;
+            /* like rayon's workers: spin briefly for the next fork before going to sleep */
+            pthread_mutex_unlock(&g_fj.mu);
+            int seen = 0;
+            for (int spin = 0; spin < 20000 && !seen; spin++) {
+                seen = *(volatile int *)&g_fj.nq || *(volatile int *)&g_fj.stop;
+                fj_pause();
+            }
+            pthread_mutex_lock(&g_fj.mu);
+            if (!seen && !g_fj.nq && !g_fj.stop) pthread_cond_wait(&g_fj.cv, &g_fj.mu);
+            continue;
+        }
+        pthread_mutex_unlock(&g_fj.mu);
+        t->fn(t->arg);
+        pthread_mutex_lock(&g_fj.mu);
+        t->done = 1;
+        pthread_cond_broadcast(&g_fj.cv);
+    }
+    pthread_mutex_unlock(&g_fj.mu);
+    return NULL;
+}
+static void fj_start(int threads) { /* `threads` in total, the caller included */
+    g_fj.stop = 0;
+    g_fj.nworkers = threads - 1 > 15 ? 15 : threads - 1;
+    for (int i = 0; i < g_fj.nworkers; i++) pthread_create(&g_fj.th[i], NULL, fj_worker, NULL);
+    g_fj_on = 1;
+}
+static void fj_stop(void) {
+    pthread_mutex_lock(&g_fj.mu);
+    g_fj.stop = 1;
+    pthread_cond_broadcast(&g_fj.cv);
+    pthread_mutex_unlock(&g_fj.mu);
+    for (int i = 0; i < g_fj.nworkers; i++) pthread_join(g_fj.th[i], NULL);
+    g_fj.nworkers = 0;
+    g_fj_on = 0;
+}
+/* run n tasks: the first inline, the rest offered to the pool; while waiting, run queued tasks */
+static void fj_run(fj_task *tasks, int n) {
+    if (!g_fj_on || n <= 1) {
+        for (int i = 0; i < n; i++) tasks[i].fn(tasks[i].arg);
+        return;
+    }
+    pthread_mutex_lock(&g_fj.mu);
+    for (int i = n - 1; i >= 1; i--) {
+        tasks[i].done = 0;
+        g_fj.q[g_fj.nq++] = &tasks[i];
+    }
+    pthread_cond_broadcast(&g_fj.cv);
+    pthread_mutex_unlock(&g_fj.mu);
+    tasks[0].fn(tasks[0].arg);
+    pthread_mutex_lock(&g_fj.mu);
+    for (;;) {
+        int pending = 0;
+        for (int i = 1; i < n; i++) pending += !tasks[i].done;
+        if (!pending) break;
+        fj_task *t = fj_pop_locked();
+        if (t) {
+            pthread_mutex_unlock(&g_fj.mu);
+            t->fn(t->arg);
+            pthread_mutex_lock(&g_fj.mu);
+            t->done = 1;
+            pthread_cond_broadcast(&g_fj.cv);
+        } else {
+            pthread_mutex_unlock(&g_fj.mu);
+            for (int spin = 0; spin < 2000; spin++) {
+                int all = 1;
+                for (int i = 1; i < n; i++) all &= tasks[i].done;
+                if (all || *(volatile int *)&g_fj.nq) break;
+                fj_pause();
+            }
+            pthread_mutex_lock(&g_fj.mu);
+        }
+    }
+    pthread_mutex_unlock(&g_fj.mu);
+}
+
 static void cc_reserve(chan_cache *c, uint32_t n) {
     if (n <= c->cap) return;
     for (int i = 0; i < 4; i++) c->fixed_buf[i] = (int32_t *)realloc(c->fixed_buf[i], 4u * n);
@@ -877,6 +987,24 @@ static int encode_lpc_subframe(const orc_options *o, int use_rice2, chan_cache *
     return rc;
 }
 
+typedef struct {
+    const orc_options *o;
+    int use_rice2;
+    chan_cache *c;
+    recorder *r;
+    const int32_t *ch;
+    uint32_t n, bps, wasted;
+    int rc;
+} sub_job;
+static void run_fixed_job(void *a) {
+    sub_job *j = (sub_job *)a;
+    j->rc = encode_fixed_subframe(j->o, j->use_rice2, j->c, j->r, j->ch, j->n, j->bps, j->wasted);
+}
+static void run_lpc_job(void *a) {
+    sub_job *j = (sub_job *)a;
+    j->rc = encode_lpc_subframe(j->o, j->use_rice2, j->c, j->r, j->ch, j->n, j->bps, j->wasted);
+}
+
 /* ------------------------------------------------------------------ */
 /* encode_subframe, encode.rs:2849-2980.  *status: 0 ok, <0 fatal       */
 /* ------------------------------------------------------------------ */
@@ -918,8 +1046,13 @@ static recorder *encode_subframe(const orc_options *o, int use_rice2, chan_cache
     int fatal = 0;
     if (o->max_lpc_order > 0) {
         bw_clear(&c->lpc_out.w);
-        int f = encode_fixed_subframe(o, use_rice2, c, &c->fixed_out, ch, n, bps, wasted);
-        int l = encode_lpc_subframe(o, use_rice2, c, &c->lpc_out, ch, n, bps, wasted);
+        /* join(fixed, lpc), encode.rs:2906-2928 (disjoint scratch: fixed_buf / fixed_out vs
+           window, windowed, residuals / lpc_out) */
+        sub_job jf = {o, use_rice2, c, &c->fixed_out, ch, n, bps, wasted, 0}, jl = jf;
+        jl.r = &c->lpc_out;
+        fj_task tk[2] = {{run_fixed_job, &jf, 0}, {run_lpc_job, &jl, 0}};
+        fj_run(tk, 2);
+        int f = jf.rc, l = jl.rc;
         if (f == ORC_ERR_UNSUPPORTED || l == ORC_ERR_UNSUPPORTED) fatal = ORC_ERR_UNSUPPORTED;
         if (f == 0 && l == 0)
             best = (c->lpc_out.w.total < c->fixed_out.w.total) ? &c->lpc_out : &c->fixed_out;
@@ -1074,6 +1207,21 @@ static inline uint64_t abs_u64(int32_t v) {
     return (uint64_t)(v < 0 ? (uint32_t)0 - (uint32_t)v : (uint32_t)v);
 }
 
+typedef struct {
+    const orc_options *o;
+    int use_rice2;
+    chan_cache *c;
+    const int32_t *ch;
+    uint32_t n, bps;
+    int all0;
+    recorder *out;
+    int st;
+} chan_job;
+static void run_chan_job(void *a) {
+    chan_job *j = (chan_job *)a;
+    j->out = encode_subframe(j->o, j->use_rice2, j->c, j->ch, j->n, j->bps, j->all0, &j->st);
+}
+
 static int encode_frame_inner(const orc_options *o, enc_caches *cache, uint32_t sample_rate,
                               uint32_t bps, uint32_t n_channels, const int32_t *const *chs,
                               uint32_t n, uint64_t frame_number, int subset, int use_rice2,
@@ -1102,21 +1250,27 @@ static int encode_frame_inner(const orc_options *o, enc_caches *cache, uint32_t 
             cache->cap = n;
         }
         if (o->exhaustive) { /* :2676-2847 */
-            recorder *lr = encode_subframe(o, use_rice2, &cache->left, left, n, bps, 0, &st);
-            if (st) return st;
-            recorder *rr = encode_subframe(o, use_rice2, &cache->right, right, n, bps, 0, &st);
-            if (st) return st;
+            /* try_join(left, right), encode.rs:2690-2712 */
+            chan_job jl = {o, use_rice2, &cache->left, left, n, bps, 0, NULL, 0};
+            chan_job jr = {o, use_rice2, &cache->right, right, n, bps, 0, NULL, 0};
+            fj_task tlr[2] = {{run_chan_job, &jl, 0}, {run_chan_job, &jr, 0}};
+            fj_run(tlr, 2);
+            if (jl.st) return jl.st;
+            if (jr.st) return jr.st;
+            recorder *lr = jl.out, *rr = jr.out;
             if (bps + 1 <= 32 && o->mid_side) {
                 for (uint32_t i = 0; i < n; i++) {
                     cache->average[i] = (int32_t)((uint32_t)left[i] + (uint32_t)right[i]) >> 1;
                     cache->difference[i] = (int32_t)((uint32_t)left[i] - (uint32_t)right[i]);
                 }
-                recorder *ar =
-                    encode_subframe(o, use_rice2, &cache->avg, cache->average, n, bps, 0, &st);
-                if (st) return st;
-                recorder *dr = encode_subframe(o, use_rice2, &cache->diff, cache->difference, n,
-                                               bps + 1, 0, &st);
-                if (st) return st;
+                /* try_join(average, difference), encode.rs:2715-2745 */
+                chan_job ja = {o, use_rice2, &cache->avg, cache->average, n, bps, 0, NULL, 0};
+                chan_job jd = {o, use_rice2, &cache->diff, cache->difference, n, bps + 1, 0, NULL, 0};
+                fj_task tad[2] = {{run_chan_job, &ja, 0}, {run_chan_job, &jd, 0}};
+                fj_run(tad, 2);
+                if (ja.st) return ja.st;
+                if (jd.st) return jd.st;
+                recorder *ar = ja.out, *dr = jd.out;
                 uint32_t tot[4] = {lr->w.total + rr->w.total, lr->w.total + dr->w.total,
                                    dr->w.total + rr->w.total, ar->w.total + dr->w.total};
                 int b = 0;
@@ -1209,13 +1363,23 @@ static int encode_frame_inner(const orc_options *o, enc_caches *cache, uint32_t 
             subs[1] = encode_subframe(o, use_rice2, &cache->channels[1], c1, n, b1, a1, &st);
             if (st) return st;
         }
-    } else {
+    } else { /* vec_map over the channels, encode.rs:2393-2402 */
+        chan_job jc[ORC_MAX_CHANNELS];
+        fj_task tc[ORC_MAX_CHANNELS];
         for (uint32_t c = 0; c < n_channels; c++) {
             int all0 = 1;
             for (uint32_t i = 0; i < n; i++)
                 if (chs[c][i]) { all0 = 0; break; }
-            subs[c] = encode_subframe(o, use_rice2, &cache->channels[c], chs[c], n, bps, all0, &st);
-            if (st) return st;
+            chan_job j = {o, use_rice2, &cache->channels[c], chs[c], n, bps, all0, NULL, 0};
+            jc[c] = j;
+            tc[c].fn = run_chan_job;
+            tc[c].arg = &jc[c];
+            tc[c].done = 0;
+        }
+        fj_run(tc, (int)n_channels);
+        for (uint32_t c = 0; c < n_channels; c++) {
+            if (jc[c].st) return jc[c].st;
+            subs[c] = jc[c].out;
             source[c] = (uint8_t)c;
         }
     }
@@ -1651,6 +1815,8 @@ int orc_encode_stream_vc(const orc_options *opts, const orc_vorbis_comment *vc,
     int32_t *planar = (int32_t *)malloc(4u * frame_samples);
     const int32_t *chs[ORC_MAX_CHANNELS];
 
+    const int fork_join = threads < -1;
+    if (fork_join) fj_start(-threads); /* reference-shaped: frames sequential, tasks forked per frame */
     if (threads > 1) {
         uint64_t nblocks = whole + ((n_interleaved - whole * frame_samples) ? 1 : 0);
         uint64_t last_len = (n_interleaved - whole * frame_samples) ? rem / channels : block;
@@ -1721,6 +1887,7 @@ int orc_encode_stream_vc(const orc_options *opts, const orc_vorbis_comment *vc,
     }
     if (rc == 0) rc = encoder_finalize(&e);
 done:
+    if (fork_join) fj_stop();
     free(planar);
     if (stats) {
         stats->frames = e.frame_number;

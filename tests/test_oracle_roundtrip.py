@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import _oracle as orc
-from _pcm import generate_sine_1, generate_sine_2, read_raw, synth
+from _pcm import generate_sine_1, generate_sine_2, read_raw, synth, synth_fast
 
 
 def roundtrip(opts, rate, bps, ch, pcm, total_known=True, threads=1):
@@ -135,3 +135,15 @@ def test_error_paths():
     assert orc.encode_stream(o, 44100, 16, 9, z)[0] == -3     # ExcessiveChannels
     assert orc.encode_stream(o, 44100, 16, 3, z)[0] == -4     # SamplesNotDivisibleByChannels
     assert orc.encode_stream(orc.options("default", block_size=15), 44100, 16, 1, z)[0] == -10
+
+
+def test_fork_join_task_structure_gives_the_same_bytes():
+    """threads < 0: the reference's per-frame fork-join (L || R, M || S, FIXED || LPC; vec_map over
+    the channels above two) on a small pool -- only the CPU baseline's timing differs, never a byte."""
+    for ch, bps, preset in ((2, 16, "default"), (2, 24, "best"), (5, 16, "default"), (1, 8, "fast")):
+        pcm = synth_fast(70 + ch, ch, bps, 4096 * 6 + 50)
+        rc, ref, _ = orc.encode_stream(orc.options(preset), 44100, bps, ch, pcm, total_known=True, threads=1)
+        assert rc == 0
+        for th in (-2, -4, -9):
+            rc, out, _ = orc.encode_stream(orc.options(preset), 44100, bps, ch, pcm, total_known=True, threads=th)
+            assert rc == 0 and out == ref
