@@ -57,12 +57,21 @@ bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t 
     if (p.max_lpc_order > 16) {  // lags up to 32: two blocks of history, frame a multiple of 64
         if (n % 64 != 0) return false;
         const uint32_t groups = (nframes * p.ncand + 63) / 64;
-        if (stereo)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
+        static const bool private_deep = getenv("FLACGPU_AC_PRIVATE") != nullptr;
+        if (private_deep) {
+            if (stereo)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                                   nframes, n, win);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
+                                   nframes, n, win);
+        } else if (stereo) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
                                nframes, n, win);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<false>), dim3(groups), dim3(256), 0, st, p, frame0,
                                nframes, n, win);
+        }
         return true;
     }
     if (stereo) launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);

@@ -29,6 +29,7 @@ class GpuAnalyzer:
         self._h = C.c_void_p(None)
         self.block_size, self.channels, self.max_frames = block_size, channels, max_frames
         self.bits_per_sample = bits_per_sample
+        self.last_frames = 0   # frames of the batch submitted last (sizes the offsets arrays)
         rc = L.flacgpu_create(C.byref(o), bits_per_sample, channels, device, max_frames,
                               C.byref(self._h))
         if rc:
@@ -53,6 +54,7 @@ class GpuAnalyzer:
 
     def analyze(self, pcm, n_frames, last_frame_len, layout=LAYOUT_INTERLEAVED):
         """pcm: host int32 array.  Returns (frame plans, subframe plans, residuals)."""
+        self.last_frames = n_frames
         pcm = np.ascontiguousarray(pcm, dtype=np.int32)
         plans, subs, res = self._alloc(n_frames)
         rc = _lib.lib().flacgpu_analyze(
@@ -64,6 +66,7 @@ class GpuAnalyzer:
 
     def analyze_device(self, device_ptr, n_frames, last_frame_len, layout=LAYOUT_INTERLEAVED,
                        stream=None):
+        self.last_frames = n_frames
         rc = _lib.lib().flacgpu_analyze_device(self._h, C.c_void_p(device_ptr), layout, n_frames,
                                                last_frame_len, C.c_void_p(stream or 0))
         if rc:
@@ -93,6 +96,7 @@ class GpuAnalyzer:
     def encode_device(self, device_ptr, n_frames, last_frame_len, first_frame_number, sample_rate,
                       layout=LAYOUT_INTERLEAVED, stream=None):
         """analyze_device + pack_device in one call (see set_two_ranges)."""
+        self.last_frames = n_frames
         rc = _lib.lib().flacgpu_encode_device(self._h, C.c_void_p(device_ptr), layout, n_frames,
                                               last_frame_len, first_frame_number, sample_rate,
                                               C.c_void_p(stream or 0))
@@ -106,8 +110,12 @@ class GpuAnalyzer:
         if rc:
             raise GpuError(rc, "flacgpu_pack_device")
 
-    def fetch_frames(self, n_frames):
+    def fetch_frames(self, n_frames=None):
         """Returns (bytes, offsets[n_frames+1]) of the frames packed on the device."""
+        held = self.last_frames or n_frames
+        if n_frames is not None and held != n_frames:
+            raise ValueError(f"the context holds a batch of {held} frames, not {n_frames}")
+        n_frames = held
         off = (C.c_uint64 * (n_frames + 1))()
         total = C.c_uint64(0)
         L = _lib.lib()
@@ -123,6 +131,7 @@ class GpuAnalyzer:
     def encode_frames(self, pcm, n_frames, last_frame_len, first_frame_number, sample_rate,
                       layout=LAYOUT_INTERLEAVED):
         """analyze + pack + fetch on host PCM; returns (bytes, offsets)."""
+        self.last_frames = n_frames
         pcm = np.ascontiguousarray(pcm, dtype=np.int32)
         cap = pcm.size * 4 + n_frames * 128 + 1024
         buf = np.empty(cap, dtype=np.uint8)
@@ -140,6 +149,7 @@ class GpuAnalyzer:
         """The asynchronous host path in one go (flacgpu_encode_packed_async -> frames_ready ->
         fetch_frames_async -> wait): pcm_le = interleaved little-endian samples of bytes_per_sample
         bytes (uint8 array).  Returns (bytes, offsets)."""
+        self.last_frames = n_frames
         L = _lib.lib()
         src = np.ascontiguousarray(pcm_le, dtype=np.uint8)
         hin = hout = None

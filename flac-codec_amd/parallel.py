@@ -21,8 +21,13 @@ def shard_range(total_frames, world, rank):
     return total_frames * rank // world, total_frames * (rank + 1) // world
 
 
-def local_counters(analyzer, n_frames):
-    """{frames, bytes, min_frame, max_frame} of the frames this rank packed last."""
+def local_counters(analyzer, n_frames=None):
+    """{frames, bytes, min_frame, max_frame} of the frames this rank packed last (the offsets array is
+    sized by the batch the context holds, whatever the caller believes)."""
+    held = getattr(analyzer, "last_frames", 0) or n_frames
+    if n_frames is not None and held != n_frames:
+        raise ValueError(f"the context holds a batch of {held} frames, not {n_frames}")
+    n_frames = held
     off = (C.c_uint64 * (n_frames + 1))()
     total = C.c_uint64(0)
     rc = _lib.lib().flacgpu_fetch_frames(analyzer._h, None, 0, off, C.byref(total))
