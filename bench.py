@@ -497,6 +497,8 @@ def main():
                 key = names.get(dom, dom)
                 prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
                 t = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                if key + "p" in t:      # the persistent variant of the kernel (k_cand64p)
+                    key += "p"
                 if key in t:
                     traffic = t[key]["hbm_bytes"]
                     traffic_src = {"source": "profiles/" + prof[-1], "kernel": key,

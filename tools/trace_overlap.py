@@ -42,10 +42,10 @@ for n, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {n:24s} {sum(v) / len(v) / 1e6:.4f}  x{len(v):4d}  {100 * sum(v) / tot:.1f}%")
 # which kernels run while k_cand64 runs
 co = collections.Counter()
-cands = [r for r in win if r[2] == "k_cand64"]
+cands = [r for r in win if r[2].startswith("k_cand64")]
 for s, e, n, q in cands:
     for s2, e2, n2, q2 in win:
-        if n2 != "k_cand64" or (s2, e2) != (s, e):
+        if not n2.startswith("k_cand64") or (s2, e2) != (s, e):
             ov = min(e, e2) - max(s, s2)
             if ov > 0:
                 co[n2] += ov
