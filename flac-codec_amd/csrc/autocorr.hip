@@ -21,6 +21,13 @@ void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32
     // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
     // instructions).
     static const bool private_tiles = getenv("FLACGPU_AC_PRIVATE") != nullptr;  // previous kernel (A/B runs)
+    if constexpr (STEREO) {
+        if (p.inter) {   // interleaved input read in place (the host selects this only with the 4-way split)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
+                               frame0, nframes, n, win);
+            return;
+        }
+    }
     if (!private_tiles) {  // shared conversion through LDS
         if (p.ac_split == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
@@ -58,7 +65,10 @@ bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t 
         if (n % 64 != 0) return false;
         const uint32_t groups = (nframes * p.ncand + 63) / 64;
         static const bool private_deep = getenv("FLACGPU_AC_PRIVATE") != nullptr;
-        if (private_deep) {
+        if (stereo && p.inter) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true, true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                               nframes, n, win);
+        } else if (private_deep) {
             if (stereo)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,
                                    nframes, n, win);

@@ -94,6 +94,8 @@ struct flacgpu_ctx {
     uint64_t packed_cap = 0;        // bytes
     bool packed_valid = false;
     bool resid_valid = false;       // d_resid holds the rows of the last analysed batch
+    bool planar_valid = true;       // false: the last batch was analysed from the caller's interleaved PCM in
+    const int32_t *direct_src = nullptr;   //   place (direct_src); d_planar is filled on demand (ensure_planar)
     Params last_params;
     uint32_t window_last_len = 0;
     hipStream_t own_stream = nullptr;
@@ -480,6 +482,7 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.fcount = n_frames;
     p.ac_split = (uint32_t)c->lag_split;
     p.planar = c->d_planar;
+    p.inter = nullptr;
     p.window_full = c->d_window_full;
     p.window_last = c->d_window_last;
     p.log2_thr = c->d_log2_thr;
@@ -517,6 +520,36 @@ static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
 }
 
 // packed_bytes != 0: the PCM sits in c->d_in as interleaved little-endian samples of that many bytes
+// Whether a batch of interleaved i32 PCM can be analysed and assembled in place (Params::inter): stereo with
+// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks, LPC on, the exhaustive search
+// (k_stereo_stats reads planar rows), and every stage on its wave kernel -- none of the knobs that select an
+// older or generic kernel (they read Params::planar).
+static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
+    const bool off = getenv("FLACGPU_NO_DIRECT") || getenv("FLACGPU_NO_FAST") || getenv("FLACGPU_NO_W64") ||
+                            getenv("FLACGPU_NO_PERSIST") || getenv("FLACGPU_NO_AC3") || getenv("FLACGPU_AC_PRIVATE") ||
+                            getenv("FLACGPU_EXPERIMENT_MFMA_AC") || getenv("FLACGPU_NO_FUSED_PACK") ||
+                            getenv("FLACGPU_NO_FRAME64");
+    const uint32_t B = p.block_size;
+    return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B && p.exhaustive &&
+           p.max_lpc_order > 0 && p.max_po <= 6 && p.ac_split != 2 &&
+           (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
+}
+
+// d_planar of the last batch, for the consumers outside the hot path (verification against the input,
+// residual rows, flacgpu_device_buffer): a DIRECT batch never split its channels, so K0 runs now, from the
+// caller's buffer
+static int ensure_planar(flacgpu_ctx *c) {
+    if (c->planar_valid) return FLACGPU_OK;
+    if (!c->direct_src || c->last_frames == 0) return FLACGPU_OK;
+    if (int rc = ctx_sync(c)) return rc;
+    (void)launch_k0(c, c->direct_src, FLACGPU_LAYOUT_INTERLEAVED, c->last_frames, c->last_len, 0, c->last_frames,
+                    ctx_stream(c));
+    HIP_TRY(hipGetLastError());
+    if (int rc = ctx_sync(c)) return rc;
+    c->planar_valid = true;
+    return FLACGPU_OK;
+}
+
 static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
                         uint32_t last_len, hipStream_t st, uint32_t packed_bytes);
 
@@ -573,11 +606,20 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
 
     const uint32_t ncb = n_frames * c->ncand;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)ncb), st));  // + d_orbits
+    // DIRECT input: interleaved i32 stereo PCM of whole 4096-sample blocks is read in place by the
+    // autocorrelation, candidate and frame kernels (no K0 split; the ORs come out of k_autocorr4, so
+    // k_candinfo runs after it) -- see kernels/autocorr.inc.  The caller's buffer is then the only copy of
+    // the input: it must stay valid until the batch's results were fetched (include/flacenc_gpu.h).
+    const bool direct = !packed_bytes && layout == FLACGPU_LAYOUT_INTERLEAVED && direct_input_ok(c, p, last_len);
+    c->planar_valid = !direct;
+    c->direct_src = direct ? d_pcm : nullptr;
+    if (direct) p.inter = d_pcm;
     // K0 (+ OR of every candidate's samples -> wasted bits)
     const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
-    begin(0);
-    bool have_orbits = false;
-    if (packed_bytes) {
+    if (!direct) begin(0);
+    bool have_orbits = direct;
+    if (direct) {
+    } else if (packed_bytes) {
         launch_k0_packed(c, packed_bytes, n_frames, last_len, st);
         have_orbits = true;
     } else if (planar_direct) {
@@ -592,7 +634,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         begin(1);
         hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
     }
-    hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
+    if (!direct) hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
     // block sizes, a short last frame, candidates wider than 25 bits) the generic LDS ones
     const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
@@ -628,6 +670,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
         if (full) dispatch_autocorr(H, p, 0, full, B, c->d_window_full, st);
         if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
+        if (direct) hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
         begin(4);
         launch_lpc(p, (ncb + 63) / 64, st);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
@@ -742,6 +785,7 @@ static int resolve_order_ties(flacgpu_ctx *c) {
 
 static int ensure_residual_rows(flacgpu_ctx *c) {
     if (c->resid_valid) return FLACGPU_OK;
+    if (int rc = ensure_planar(c)) return rc;   // k_emit reads planar rows
     if (int rc = ctx_sync(c)) return rc;
     const Params &p = c->last_params;
     if (p.block_size > LDS_BLOCK_LIMIT)
@@ -974,6 +1018,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     HIP_TRY(hipStreamWaitEvent(st0, c->ev_join, 0));
     HIP_TRY(hipGetLastError());
     c->resid_valid = false;
+    c->planar_valid = true;
+    c->direct_src = nullptr;
     c->last_frames = n_frames;
     c->last_len = last_len;
     c->last_params = p;
@@ -1059,6 +1105,8 @@ int flacgpu_pack_plans(flacgpu_ctx *c, const int32_t *pcm, uint32_t n_frames, ui
     c->last_len = last_len;
     c->last_stream = st;
     c->resid_valid = false;
+    c->planar_valid = true;
+    c->direct_src = nullptr;
     c->packed_valid = false;
     HIP_TRY(hipStreamSynchronize(st));   // the host arrays may go away
     return pack_impl(c, first_frame_number, sample_rate, st, nullptr);
@@ -1481,6 +1529,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     q.out_words = c->d_packed;
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
+    if (int rc = ensure_planar(c)) return rc;
     if (int rc = ctx_sync(c)) return rc;
     HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * (4 + (size_t)p.n_frames), st));
     // compare against the planar PCM the analysis consumed, when it is the context's own copy
@@ -1561,7 +1610,7 @@ void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     case 0: return c->d_fplan;
     case 1: return c->d_out;
     case 2: return ensure_residual_rows(c) == FLACGPU_OK ? c->d_resid : nullptr;
-    case 3: return c->d_planar;
+    case 3: return ensure_planar(c) == FLACGPU_OK ? c->d_planar : nullptr;
     case 4: return c->d_packed;
     case 5: return c->d_frame_off;
     default: return nullptr;

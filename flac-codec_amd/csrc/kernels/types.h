@@ -65,6 +65,10 @@ struct Params {
     uint32_t ac_split;                             // waves the lags of k_autocorr3 are split over (2 or 4)
     // buffers
     const int32_t *planar;
+    // DIRECT input: the batch's interleaved stereo PCM ([frame][sample][l, r], every frame of block_size
+    // samples) read by k_autocorr4 / k_cand64p / k_frame64 themselves -- no K0 split, `planar` is not
+    // written.  nullptr: the kernels read `planar`
+    const int32_t *inter;
     const double *window_full, *window_last;
     const double *log2_thr;                        // [128], index e + 64
     CandInfo *cinfo;
@@ -126,6 +130,8 @@ void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st);
 void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 // cand.hip
 void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
+// cand_direct.hip
+void launch_cand64_direct(const Params &p, uint32_t blocks, hipStream_t st);
 // autocorr.hip
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st);
@@ -142,6 +148,7 @@ void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t f
 hipError_t pack_set_attributes(size_t pack_lds);
 // frame64_a.hip / frame64_b.hip / frame64_c.hip
 void launch_frame64_4096(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
+void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_deep(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_short(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds,
                           hipStream_t st);

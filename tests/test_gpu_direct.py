@@ -1,0 +1,118 @@
+"""DIRECT input (Params::inter): interleaved i32 stereo PCM of whole 4096-sample blocks is analysed and
+assembled in place -- no K0 split, the wasted-bits ORs come out of the autocorrelation kernel, whose sums
+are scaled by 2^(-2 wasted) instead of being formed from shifted samples (kernels/autocorr.inc).  Every case
+must give the oracle's bytes, the bytes of the K0 path (FLACGPU_NO_DIRECT), and survive the consumers that
+need planar rows afterwards (verification against the input, residual rows for the host packer)."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import synth_fast
+
+pytestmark = pytest.mark.gpu
+B = 4096
+
+
+def encode(pcm, bps, max_lpc, monkeypatch, direct, mid_side=True, rate=48000, first=5):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    if direct:
+        monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+    else:
+        monkeypatch.setenv("FLACGPU_NO_DIRECT", "1")
+    n = pcm.size // (2 * B)
+    an = GpuAnalyzer(B, 6, max_lpc, mid_side, True, 2, 0.5, bps, 2, max_frames=n)
+    data, off = an.encode_frames(pcm, n, B, first, rate)
+    kernels_ms = None
+    an.set_timing(True)
+    an.analyze(pcm, n, B)
+    kernels_ms = an.kernel_ms()
+    an.set_timing(False)
+    an.analyze(pcm, n, B)
+    an.pack_device(first, rate)
+    res, _ = an.verify_device(rate, first)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+    plans, subs, resid = an.fetch(n, want_residuals=True)
+    st = an.stats()
+    an.close()
+    return data, off, kernels_ms, (plans, subs, resid), st
+
+
+def check(pcm, bps, monkeypatch, max_lpc=12, mid_side=True, rate=48000):
+    from flac_codec_amd.gpu import host_pack_frames
+
+    first = 5
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    n = pcm.size // (2 * B)
+    d_data, d_off, d_ms, d_plans, _ = encode(pcm, bps, max_lpc, monkeypatch, True, mid_side, rate, first)
+    k_data, k_off, k_ms, _, _ = encode(pcm, bps, max_lpc, monkeypatch, False, mid_side, rate, first)
+    assert "k_deinterleave" not in d_ms and "k_deinterleave" in k_ms   # the split pass really was skipped
+    assert d_off == k_off and d_data == k_data
+    oopts = orc_options_for(B, 6, max_lpc, mid_side, True)
+    for f, planar in enumerate(planar_frames(pcm, 2, B)):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)
+        assert rc == 0 and d_data[d_off[f]:d_off[f + 1]] == fb, f
+    # residual rows fetched after a direct analysis (planar rows made on demand) feed the host packer
+    plans, subs, resid = d_plans
+    h_data, h_off = host_pack_frames(rate, bps, 2, first, n, B, plans, subs, resid, threads=2)
+    assert h_off == d_off and h_data == d_data
+
+
+def test_plain_and_order32(monkeypatch):
+    check(synth_fast(900, 2, 24, B * 9), 24, monkeypatch)
+    check(synth_fast(901, 2, 16, B * 5), 16, monkeypatch, max_lpc=8, rate=44100)
+    check(synth_fast(902, 2, 24, B * 4), 24, monkeypatch, max_lpc=32, rate=96000)
+    check(synth_fast(903, 2, 20, B * 3), 20, monkeypatch, mid_side=False)
+
+
+def test_wasted_bits_per_candidate(monkeypatch):
+    """Different trailing-zero counts on L, R, mid and side: the scaling by 2^(-2 wasted) is per candidate."""
+    x = synth_fast(910, 2, 16, B * 6).reshape(-1, 2).astype(np.int64)
+    both = (x << 5).astype(np.int32)                               # L, R, side: 5; mid: 4 or more
+    check(both.reshape(-1), 24, monkeypatch)
+    left = x.copy()
+    left[:, 0] <<= 3                                               # L: 3, R: 0, mid / side: 0
+    check(left.astype(np.int32).reshape(-1), 24, monkeypatch)
+    odd = x.copy()
+    odd[:, 0] = (odd[:, 0] << 2) | 2                               # L: 1 ... and a frame-dependent mix
+    odd[:, 1] <<= 2
+    check(odd.astype(np.int32).reshape(-1), 24, monkeypatch)
+    eight = (x[: B * 3] << 8).astype(np.int32)                     # 16 significant bits in a 24-bit stream
+    check(eight.reshape(-1), 24, monkeypatch, max_lpc=32)
+
+
+def test_constant_silent_and_noise(monkeypatch):
+    x = synth_fast(920, 2, 24, B * 6).reshape(-1, 2).copy()
+    x[:, 1] = 0                                                    # R all zero: CONSTANT; side == L, mid = L >> 1
+    check(x.reshape(-1), 24, monkeypatch)
+    y = synth_fast(921, 2, 24, B * 6).reshape(-1, 2).copy()
+    y[B:3 * B] = 0                                                 # two silent frames in the middle
+    y[3 * B:4 * B, 0] = y[3 * B:4 * B, 1]                          # L == R: side all zero
+    check(y.reshape(-1), 24, monkeypatch)
+    rng = np.random.Generator(np.random.PCG64(922))
+    check(rng.integers(-(1 << 23), 1 << 23, size=B * 2 * 3, dtype=np.int64).astype(np.int32), 24, monkeypatch)
+    check(np.full(B * 2 * 2, -(1 << 23), dtype=np.int32), 24, monkeypatch)   # DC at the negative rail
+
+
+def test_device_buffer_input(monkeypatch):
+    """The bench's entry point: PCM already in HBM, owned by the caller (a torch tensor)."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+    n = 40
+    pcm = synth_fast(930, 2, 24, B * n)
+    d = torch.from_numpy(pcm).cuda()
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=n)
+    for first in (0, 1000):
+        an.encode_device(d.data_ptr(), n, B, first, 48000)
+        data, off = an.fetch_frames(n)
+        oopts = orc_options_for(B, 6, 12, True, True)
+        for f, planar in enumerate(planar_frames(pcm, 2, B)):
+            rc, fb, _ = orc.encode_frame(oopts, 48000, 24, planar, frame_number=first + f)
+            assert rc == 0 and data[off[f]:off[f + 1]] == fb, f
+        res, _ = an.verify_device(48000, first)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+    an.close()
