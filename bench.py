@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-batch-frames", type=int, default=0,
                     help="batch_frames of the writers in the end_to_end block (0: the library default)")
-    ap.add_argument("--contexts", type=int, default=3, choices=(1, 2, 3, 4),
+    ap.add_argument("--contexts", type=int, default=4, choices=(1, 2, 3, 4, 5, 6),
                     help="encoder contexts consecutive batches rotate through (multi-buffering)")
     ap.add_argument("--lag-split", type=int, default=0, choices=(0, 2, 4),
                     help="waves the autocorrelation lags are split over (0: the library default)")
