@@ -11,12 +11,12 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
     // persistent variant with LDS prefetch: 4096-sample blocks, order <= 16, enough groups to go round
     static const bool no_persist = getenv("FLACGPU_NO_PERSIST") != nullptr;
     if (p.inter) {   // interleaved stereo input read in place: persistent kernels only (cand_direct.hip)
         launch_cand64_direct(p, blocks, st);
-        return;
+        return true;
     }
     if (!no_persist && B == FN && p.max_lpc_order > 16) {
         static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
@@ -24,7 +24,7 @@ void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
         const bool stereo = p.stereo4 && p.ncand == 4;
         if (stereo) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, true>), dim3(grid), dim3(WG), 0, st, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, false>), dim3(grid), dim3(WG), 0, st, p);
-        return;
+        return stereo;
     }
     if (!no_persist && B == FN && p.max_lpc_order <= 16) {
         static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
@@ -32,11 +32,11 @@ void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
         const bool stereo = p.stereo4 && p.ncand == 4;
         if (stereo) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true>), dim3(grid), dim3(WG), 0, st, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, false>), dim3(grid), dim3(WG), 0, st, p);
-        return;
+        return stereo;
     }
     if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks only
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 32>), dim3(blocks), dim3(WG), 0, st, p);
-        return;
+        return false;
     }
     switch (B) {
 #define X(n, spl) case n: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<spl, 16>), dim3(blocks), dim3(WG), 0, st, p); break;
@@ -44,5 +44,6 @@ void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
 #undef X
     default: break;
     }
+    return false;
 }
 }  // namespace flacgpu_k

@@ -670,7 +670,6 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
         if (full) dispatch_autocorr(H, p, 0, full, B, c->d_window_full, st);
         if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
-        if (direct) hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
         begin(4);
         launch_lpc(p, (ncb + 63) / 64, st);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
@@ -680,12 +679,18 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
             else hipLaunchKernelGGL(k_fir_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
         }
     }
+    bool decided = false;   // the persistent stereo kernels choose the channel assignment themselves
     if (w64 && pf.fcount) {
         begin(11);
-        launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
+        decided = launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
     }
-    begin(6);
-    hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
+    if (!decided) {
+        begin(6);
+        hipLaunchKernelGGL(k_decide, dim3(n_frames), dim3(64), 0, st, p);
+    } else if (pg.fcount) {
+        begin(6);
+        hipLaunchKernelGGL(k_decide, dim3(pg.fcount), dim3(64), 0, st, pg);
+    }
     c->last_n_fast = pf.fcount;
     c->ties_checked = !lpc;
     c->ties_resolved = 0;
@@ -773,8 +778,10 @@ static int resolve_order_ties(flacgpu_ctx *c) {
         if (B > LDS_BLOCK_LIMIT) hipLaunchKernelGGL(k_fir_t<true>, dim3(pg.fcount * c->ncand), dim3(WG), 0, st, pg);
         else hipLaunchKernelGGL(k_fir_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
-    if (pf.fcount) launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
-    hipLaunchKernelGGL(k_decide, dim3(p.n_frames), dim3(64), 0, st, p);
+    bool decided = false;
+    if (pf.fcount) decided = launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
+    if (!decided) hipLaunchKernelGGL(k_decide, dim3(p.n_frames), dim3(64), 0, st, p);
+    else if (pg.fcount) hipLaunchKernelGGL(k_decide, dim3(pg.fcount), dim3(64), 0, st, pg);
     HIP_TRY(hipGetLastError());
     c->resid_valid = false;
     c->ties_resolved = n_ties;
@@ -1006,8 +1013,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
             dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
             launch_lpc(r, (ncb + 63) / 64, st);
         }
-        launch_cand64(r, B, (ncb + 3) / 4, st);
-        hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
+        if (!launch_cand64(r, B, (ncb + 3) / 4, st)) hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's
         if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
         launch_layout(r, q, st);

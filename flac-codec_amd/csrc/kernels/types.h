@@ -129,7 +129,9 @@ namespace flacgpu_k {
 void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st);
 void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 // cand.hip
-void launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
+// returns true when the kernel also chose the channel assignment and wrote out_plan / frame_plan (the
+// persistent stereo kernels: K6 in the workgroup) -- no k_decide launch for those frames then
+bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_direct.hip
 void launch_cand64_direct(const Params &p, uint32_t blocks, hipStream_t st);
 // autocorr.hip
