@@ -239,7 +239,9 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     per = pcm[: 512 * BLOCK * C]
     streams = [per] * n_streams
     usable = int(out["host"]["usable_cpus"])
-    n_threads = max(4, min(n_streams, usable))      # more workers than usable CPUs only fight for the quota
+    # one writer thread per stream: they sleep while the GPU and the shared MD5 engines work (blocking waits),
+    # so more threads than usable CPUs cost nothing and keep 64 MD5 chains in flight
+    n_threads = n_streams
     be = BatchEncoder(opts(), threads=n_threads)
     views = be.encode(streams, rate, bps, C, copy=False)      # warm-up: lanes, pinned staging, output buffers
     rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, per, total_known=True)
@@ -255,8 +257,8 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                            "byte_identical_to_oracle": True,
                            "best_Msamples/s": round(n_streams * per.size / min(times) / 1e6, 1),
                            "note": "median of 5 calls of flacenc_encode_many (C++ front end: one writer per "
-                                   "worker thread, pooled lanes, MD5 on per-stream threads); host PCM -> "
-                                   ".flac bytes in caller buffers"}
+                                   "worker thread, pooled lanes, the streams' MD5 chains on the shared 16-lane "
+                                   "AVX-512 engines, waits that sleep); host PCM -> .flac bytes in caller buffers"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
     batch = pcm[: 1024 * BLOCK * C]

@@ -40,6 +40,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -88,6 +89,7 @@ struct flacgpu_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_layout = nullptr;
     bool two_ranges = false;         // FLACGPU_TUNE_TWO_RANGES
+    bool blocking_wait = false;      // FLACGPU_TUNE_BLOCKING_WAIT
     int lag_split = 4;               // FLACGPU_TUNE_LAG_SPLIT
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
@@ -103,6 +105,13 @@ struct flacgpu_ctx {
     // asynchronous host path (flacgpu_encode_packed_async ...)
     uint64_t *h_off = nullptr;          // pinned: byte offsets of the frames of the batch in flight
     hipEvent_t ev_sizes = nullptr, ev_bytes = nullptr, ev_null = nullptr;
+    // FLACGPU_TUNE_BLOCKING_WAIT: the waits for ev_sizes / ev_bytes sleep on a condition variable that a host
+    // function queued behind the event wakes (hipEventSynchronize spins, also with hipEventBlockingSync)
+    struct HostSignal {
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t posted = 0, fired = 0;
+    } sig_sizes, sig_bytes;
     bool sizes_pending = false, bytes_pending = false;
     // last call
     uint32_t last_frames = 0, last_len = 0;
@@ -942,6 +951,13 @@ int flacgpu_set_tuning(flacgpu_ctx *c, int key, int value) {
         if (value != 2 && value != 4) break;
         c->lag_split = value;
         return FLACGPU_OK;
+    case FLACGPU_TUNE_BLOCKING_WAIT: {
+        if ((value != 0) == c->blocking_wait) return FLACGPU_OK;
+        CTX_GUARD(c);
+        if (int rc = ctx_sync(c)) return rc;   // nothing in flight while the way of waiting changes
+        c->blocking_wait = value != 0;
+        return FLACGPU_OK;
+    }
     }
     g_last_error = "flacgpu_set_tuning: unknown key / value";
     return FLACGPU_ERR_INVALID_ARG;
@@ -1378,6 +1394,36 @@ int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_samp
     return c && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample) ? 1 : 0;
 }
 
+static void host_signal_fire(void *user) {
+    auto *sg = static_cast<flacgpu_ctx::HostSignal *>(user);
+    {
+        std::lock_guard<std::mutex> lock(sg->mu);
+        sg->fired++;
+    }
+    sg->cv.notify_all();
+}
+// record `ev` on `st`; in blocking-wait mode also queue the wake-up behind it
+static int record_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &sg, hipStream_t st) {
+    HIP_TRY(hipEventRecord(ev, st));
+    if (c->blocking_wait) {
+        {
+            std::lock_guard<std::mutex> lock(sg.mu);
+            sg.posted++;
+        }
+        HIP_TRY(hipLaunchHostFunc(st, host_signal_fire, &sg));
+    }
+    return FLACGPU_OK;
+}
+static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &sg) {
+    if (c->blocking_wait) {
+        std::unique_lock<std::mutex> lock(sg.mu);
+        sg.cv.wait(lock, [&] { return sg.fired >= sg.posted; });
+        return FLACGPU_OK;
+    }
+    HIP_TRY(hipEventSynchronize(ev));
+    return FLACGPU_OK;
+}
+
 int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
                                 uint32_t n_frames, uint32_t last_len, uint64_t first_frame_number,
                                 uint32_t sample_rate) {
@@ -1403,7 +1449,7 @@ int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t 
     HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
                            hipMemcpyDeviceToHost, c->aux_stream));
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->aux_stream));
-    HIP_TRY(hipEventRecord(c->ev_sizes, c->aux_stream));
+    if (int rc = record_waitable(c, c->ev_sizes, c->sig_sizes, c->aux_stream)) return rc;
     c->sizes_pending = true;
     c->bytes_pending = false;
     return FLACGPU_OK;
@@ -1415,7 +1461,7 @@ int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *tot
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
-    HIP_TRY(hipEventSynchronize(c->ev_sizes));
+    if (int rc = wait_waitable(c, c->ev_sizes, c->sig_sizes)) return rc;
     if (!c->ties_checked) {
         if (c->h_stats[1] == 0) {
             c->ties_checked = true;   // the common case: nothing to re-decide, nothing to wait for
@@ -1437,14 +1483,14 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
-    HIP_TRY(hipEventSynchronize(c->ev_sizes));
+    if (int rc = wait_waitable(c, c->ev_sizes, c->sig_sizes)) return rc;
     const uint64_t bytes = c->h_off[c->last_frames];
     if (cap < bytes) {
         g_last_error = "output buffer too small";
         return FLACGPU_ERR_BUFFER_TOO_SMALL;
     }
     HIP_TRY(hipMemcpyAsync(out, c->d_packed, bytes, hipMemcpyDeviceToHost, c->own_stream));
-    HIP_TRY(hipEventRecord(c->ev_bytes, c->own_stream));
+    if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, c->own_stream)) return rc;
     c->bytes_pending = true;
     return FLACGPU_OK;
 }
@@ -1453,7 +1499,7 @@ int flacgpu_wait(flacgpu_ctx *c) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     CTX_GUARD(c);
     if (c->bytes_pending) {
-        HIP_TRY(hipEventSynchronize(c->ev_bytes));
+        if (int rc = wait_waitable(c, c->ev_bytes, c->sig_bytes)) return rc;
         c->bytes_pending = false;
         c->sizes_pending = false;
         return FLACGPU_OK;

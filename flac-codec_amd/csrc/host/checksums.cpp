@@ -74,9 +74,15 @@ Md5::Md5() : a_(0x67452301u), b_(0xefcdab89u), c_(0x98badcfeu), d_(0x10325476u) 
     (a) = rotl((a), (s)) + (b)
 
 void Md5::block(const uint8_t *p) {
+    uint32_t s[4] = {a_, b_, c_, d_};
+    transform(s, p);
+    a_ = s[0]; b_ = s[1]; c_ = s[2]; d_ = s[3];
+}
+
+void Md5::transform(uint32_t state[4], const uint8_t *p) {
     uint32_t x[16];
     for (int i = 0; i < 16; i++) x[i] = load_le(p + 4 * i);
-    uint32_t a = a_, b = b_, c = c_, d = d_;
+    uint32_t a = state[0], b = state[1], c = state[2], d = state[3];
     MD5_STEP(MD5_F, a, b, c, d, x[0], 0xd76aa478u, 7);   MD5_STEP(MD5_F, d, a, b, c, x[1], 0xe8c7b756u, 12);
     MD5_STEP(MD5_F, c, d, a, b, x[2], 0x242070dbu, 17);  MD5_STEP(MD5_F, b, c, d, a, x[3], 0xc1bdceeeu, 22);
     MD5_STEP(MD5_F, a, b, c, d, x[4], 0xf57c0fafu, 7);   MD5_STEP(MD5_F, d, a, b, c, x[5], 0x4787c62au, 12);
@@ -109,7 +115,7 @@ void Md5::block(const uint8_t *p) {
     MD5_STEP(MD5_I, c, d, a, b, x[6], 0xa3014314u, 15);  MD5_STEP(MD5_I, b, c, d, a, x[13], 0x4e0811a1u, 21);
     MD5_STEP(MD5_I, a, b, c, d, x[4], 0xf7537e82u, 6);   MD5_STEP(MD5_I, d, a, b, c, x[11], 0xbd3af235u, 10);
     MD5_STEP(MD5_I, c, d, a, b, x[2], 0x2ad7d2bbu, 15);  MD5_STEP(MD5_I, b, c, d, a, x[9], 0xeb86d391u, 21);
-    a_ += a; b_ += b; c_ += c; d_ += d;
+    state[0] += a; state[1] += b; state[2] += c; state[3] += d;
 }
 
 void Md5::update(const void *data, size_t len) {

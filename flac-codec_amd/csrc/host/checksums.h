@@ -16,6 +16,14 @@ public:
     void update(const void *data, size_t len);
     void digest(uint8_t out[16]) const;  // does not disturb the running state (clone + finalize)
 
+    // for the multi-buffer engine (md5_mb.cpp): one block on a bare state, the state words of this
+    // object, and whole blocks hashed outside update() (only while no partial block is buffered)
+    static void transform(uint32_t state[4], const uint8_t *p);
+    void get_state(uint32_t s[4]) const { s[0] = a_; s[1] = b_; s[2] = c_; s[3] = d_; }
+    void set_state(const uint32_t s[4]) { a_ = s[0]; b_ = s[1]; c_ = s[2]; d_ = s[3]; }
+    void add_blocks(uint64_t nblocks) { len_ += 64 * nblocks; }
+    size_t buffered() const { return static_cast<size_t>(len_ & 63); }
+
 private:
     void block(const uint8_t *p);
     uint32_t a_, b_, c_, d_;

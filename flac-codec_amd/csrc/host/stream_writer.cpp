@@ -24,6 +24,7 @@
 
 #include "bitsink.h"
 #include "checksums.h"
+#include "md5_mb.h"
 #include "flacenc_gpu.h"
 #include "flacenc_stream.h"
 #include "frame_pack.h"
@@ -31,6 +32,8 @@
 namespace {
 
 using flacenc::Md5;
+using flacenc::Md5Lane;
+using flacenc::Md5Pool;
 
 thread_local std::string g_err;
 
@@ -340,8 +343,12 @@ LanePool &lane_pool() {
 
 // The stream MD5 is one serial chain over the PCM bytes (encode.rs:571, 1292-1318): it runs on a
 // thread of its own, fed in stream order with the very buffers that are being uploaded.
+// The stream's MD5 chain, off the writer's thread: a worker thread of its own, or (use_pool) a lane of the
+// shared multi-stream engines (md5_mb.h) when many writers run side by side.
 struct Md5Worker {
     Md5 *md5 = nullptr;
+    bool use_pool = false, pool_tried = false;
+    Md5Lane *lane = nullptr;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -350,6 +357,14 @@ struct Md5Worker {
     bool stop = false;
     double busy_ms = 0;
     uint64_t push(const uint8_t *p, size_t n) {
+        if (use_pool && !pool_tried) {   // nullptr when every engine is full: the private thread then
+            pool_tried = true;
+            lane = Md5Pool::get().attach(md5);
+        }
+        if (lane) {
+            pushed = Md5Pool::get().push(lane, p, n);
+            return pushed;
+        }
         std::unique_lock<std::mutex> lock(mu);
         if (!th.joinable()) th = std::thread([this] { run(); });
         q.emplace_back(p, n);
@@ -358,8 +373,17 @@ struct Md5Worker {
         return ticket;
     }
     void wait(uint64_t ticket) {
+        if (lane) {
+            Md5Pool::get().wait(lane, ticket);
+            return;
+        }
         std::unique_lock<std::mutex> lock(mu);
         cv.wait(lock, [&] { return done >= ticket; });
+    }
+    double total_busy_ms() {
+        if (lane) return Md5Pool::get().busy_ms(lane);
+        std::lock_guard<std::mutex> lock(mu);
+        return busy_ms;
     }
     void run() {
         std::unique_lock<std::mutex> lock(mu);
@@ -379,6 +403,7 @@ struct Md5Worker {
         }
     }
     ~Md5Worker() {
+        if (lane) Md5Pool::get().detach(lane);
         {
             std::lock_guard<std::mutex> lock(mu);
             stop = true;
@@ -519,6 +544,8 @@ struct flacenc_writer {
                 return map_gpu_error(rc);
             }
         }
+        // many writers side by side (shared MD5 engines): waiting threads sleep instead of spinning
+        (void)flacgpu_set_tuning(l->gpu, FLACGPU_TUNE_BLOCKING_WAIT, o.shared_md5 ? 1 : 0);
         lanes.push_back(l);
         return 0;
     }
@@ -596,6 +623,7 @@ struct flacenc_writer {
         depth = o.pipeline_depth ? std::min<uint32_t>(o.pipeline_depth, 4u) : 2u;
         upload_width = flacgpu_packed_input_supported(gpu, bytes_per_sample) ? bytes_per_sample : 4u;
         md5_worker.md5 = &md5;
+        md5_worker.use_pool = o.shared_md5 != 0 && !getenv("FLACENC_NO_SHARED_MD5");
         return 0;
     }
 
@@ -930,7 +958,7 @@ struct flacenc_writer {
         }
         if (int e = retire_all()) return e;
         md5_worker.wait(md5_worker.pushed);
-        stats.md5_ms += md5_worker.busy_ms;
+        stats.md5_ms += md5_worker.total_busy_ms();
         return finalize_encoder();
     }
 
@@ -1168,9 +1196,18 @@ int flacenc_pack_frames(uint32_t sample_rate, uint32_t bps, uint32_t channels,
 // a time through FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) into the job's own
 // output buffer; the GPU is shared through the pooled lanes, the MD5 chains run on the writers'
 // worker threads.
-int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
-    if (!opts || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
-    if (int e = options_error(*opts)) return e;
+int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
+    if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
+    if (int e = options_error(*opts_in)) return e;
+    // several streams at a time: their MD5 chains share the multi-stream engines (one AVX-512 lane each)
+    flacenc_options shared = *opts_in;
+    if (threads >= 3 && n_jobs >= 3) {
+        shared.shared_md5 = 1;
+        // whole streams are at hand and the parallelism comes from the streams: bigger batches (fewer, larger
+        // kernels and copies per stream) than a lone streaming writer wants
+        if (shared.batch_frames == 0) shared.batch_frames = 512;
+    }
+    const flacenc_options *opts = &shared;
     std::atomic<size_t> next{0};
     const double t_begin = now_ms();
     auto work = [&]() {

@@ -93,6 +93,7 @@ class _COptions(C.Structure):
         ("comment_fields", C.POINTER(C.c_char_p)),
         ("n_comment_fields", C.c_uint32),
         ("pipeline_depth", C.c_uint32),
+        ("shared_md5", C.c_uint32),
     ]
 
 
@@ -335,6 +336,11 @@ class Options:
     def pipeline_depth(self, n):
         """Batches in flight per writer (each on its own context / HIP stream / pinned staging)."""
         self._c.pipeline_depth = n
+        return self
+
+    def shared_md5(self, on=True):
+        """Hash this stream on the shared multi-stream MD5 engines (many concurrent writers)."""
+        self._c.shared_md5 = int(bool(on))
         return self
 
     def host_pack(self, on=True):

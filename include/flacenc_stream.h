@@ -93,6 +93,10 @@ typedef struct {
                                      a context, HIP stream and pinned staging buffers of its own, so
                                      that upload, kernels, download and the MD5 of neighbouring
                                      batches overlap; 0 = default (2), at most 4 */
+    uint32_t shared_md5;          /* 1: the stream's MD5 chain runs on the shared multi-stream engines
+                                     (host/md5_mb.h: up to 16 streams per engine thread, one per AVX-512
+                                     lane) instead of on a worker thread of its own -- for callers that
+                                     encode many streams side by side; flacenc_encode_many sets it */
 } flacenc_options;
 
 void flacenc_options_default(flacenc_options *o); /* Options::default(), encode.rs:1376-1408 */
@@ -215,6 +219,12 @@ int flacenc_stream_header(const flacenc_options *opts, uint32_t sample_rate, uin
 int flacenc_streaminfo_bytes(uint32_t min_block, uint32_t max_block, uint32_t min_frame, uint32_t max_frame,
                              uint32_t sample_rate, uint32_t channels, uint32_t bits_per_sample,
                              uint64_t total_samples, const uint8_t md5[16], uint8_t out[34]);
+
+/* Test hooks of the multi-stream MD5 engine (host/md5_mb.cpp): digests of `streams` chains fed through the
+ * pool in `runs` runs of assorted lengths against the scalar implementation (returns the mismatches), and
+ * whether this host runs the 16-lane AVX-512 step. */
+int flacenc_md5_selftest(uint32_t streams, uint32_t runs, uint32_t seed);
+int flacenc_md5_simd_available(void);
 
 const char *flacenc_last_error(void);
 

@@ -9,13 +9,25 @@ from _pcm import synth_fast
 from flac_codec_amd.encode import BatchEncoder, Options
 
 per = synth_fast(5, 2, 24, 512 * 4096)
-for n_streams, threads, batch, depth in [(64, 64, 1024, 2), (64, 16, 1024, 2), (64, 16, 256, 2), (64, 8, 256, 2), (64, 32, 256, 2), (16, 16, 256, 2)]:
+CASES = [(64, 64, 1024, 2), (64, 16, 1024, 2), (64, 16, 256, 2), (64, 8, 256, 2), (64, 32, 256, 2), (16, 16, 256, 2)]
+if len(sys.argv) > 1:   # "streams,threads,batch,depth ..."
+    CASES = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
+for n_streams, threads, batch, depth in CASES:
     be = BatchEncoder(Options.best().batch_frames(batch).pipeline_depth(depth), threads=threads)
     streams = [per] * n_streams
     be.encode(streams, 48000, 24, 2, copy=False)
     ts = []
+    def throttled():
+        try:
+            return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+        except Exception:
+            return {}
+    th0, c0 = throttled(), time.process_time()
     for _ in range(7):
         t = time.perf_counter(); be.encode(streams, 48000, 24, 2, copy=False); ts.append(time.perf_counter() - t)
+    th1, c1 = throttled(), time.process_time()
+    print(f"  cpu s per call {(c1 - c0) / 7:.3f}; throttled periods +{th1.get('nr_throttled', 0) - th0.get('nr_throttled', 0)}, "
+          f"throttled ms +{(th1.get('throttled_usec', 0) - th0.get('throttled_usec', 0)) / 1e3:.0f}")
     j = be.last_jobs
     med = lambda k: round(statistics.median(x[k] for x in j), 1)
     print(f"streams {n_streams} threads {threads} batch {batch} depth {depth}: call ms {[round(x*1e3) for x in ts]} "
