@@ -178,8 +178,9 @@ def host_capacity(bytes_per_sample):
     return {"logical_cpus": ncpu, "cgroup_cpu_quota": quota, "usable_cpus": eff,
             "md5_aggregate_Msamples/s": round(n * len(buf) / bytes_per_sample / dt / 1e6, 1),
             "md5_threads": n,
-            "note": "aggregate of concurrent hashlib MD5 chains on the usable CPUs: the upper bound of the "
-                    "many-stream end-to-end rate on this box whatever the GPU does"}
+            "note": "aggregate of concurrent SCALAR MD5 chains (hashlib), one per usable CPU: what one-thread-per-stream "
+                    "hashing can reach on this box; the writers' shared 16-lane AVX-512 engines (host/md5_mb.cpp) are "
+                    "not bound by it"}
 
 
 def end_to_end(cfg, pcm, device, orc, batch_frames=0):
