@@ -26,36 +26,25 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// T[i] = floor(2^32 |sin(i + 1)|), the message word and the rotation of step i (RFC 1321, 3.4)
-constexpr uint32_t kT[64] = {
-    0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u,
-    0x698098d8u, 0x8b44f7afu, 0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u,
-    0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau, 0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u,
-    0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u, 0x676f02d9u, 0x8d2a4c8au,
-    0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
-    0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u,
-    0xf4292244u, 0x432aff97u, 0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u,
-    0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u, 0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
-constexpr int kS[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
-constexpr int word_of(int i) {
-    return i < 16 ? i : i < 32 ? (5 * i + 1) & 15 : i < 48 ? (3 * i + 5) & 15 : (7 * i) & 15;
-}
 alignas(64) const uint8_t kDummy[64] = {0};
 
 #ifdef FLACENC_MD5_X86
 // x[w] = message word w of the sixteen blocks (one per lane): a 16 x 16 transpose of 32-bit words
 __attribute__((target("avx512f,avx512bw,avx512vl"))) inline void transpose16(__m512i (&r)[16]) {
     __m512i t[16], u[16];
+#pragma GCC unroll 8
     for (int i = 0; i < 8; i++) {
         t[2 * i] = _mm512_unpacklo_epi32(r[2 * i], r[2 * i + 1]);
         t[2 * i + 1] = _mm512_unpackhi_epi32(r[2 * i], r[2 * i + 1]);
     }
+#pragma GCC unroll 4
     for (int g = 0; g < 4; g++) {   // u[4 g + j], 128-bit lane q: word 4 q + j of rows 4 g .. 4 g + 3
         u[4 * g + 0] = _mm512_unpacklo_epi64(t[4 * g + 0], t[4 * g + 2]);
         u[4 * g + 1] = _mm512_unpackhi_epi64(t[4 * g + 0], t[4 * g + 2]);
         u[4 * g + 2] = _mm512_unpacklo_epi64(t[4 * g + 1], t[4 * g + 3]);
         u[4 * g + 3] = _mm512_unpackhi_epi64(t[4 * g + 1], t[4 * g + 3]);
     }
+#pragma GCC unroll 4
     for (int j = 0; j < 4; j++) {   // a 4 x 4 transpose of 128-bit lanes per j
         const __m512i v0 = _mm512_shuffle_i32x4(u[j], u[4 + j], 0x88);
         const __m512i v1 = _mm512_shuffle_i32x4(u[j], u[4 + j], 0xdd);
@@ -68,26 +57,82 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) inline void transpose16(__m
     }
 }
 
-// one round of 16 steps; IMM = truth table of the round function on (b, c, d)
-template <int ROUND, int IMM>
-__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void round16(__m512i &a, __m512i &b, __m512i &c, __m512i &d,
-                                                                          const __m512i (&x)[16]) {
-#define FLACENC_MD5_STEP(A, B, C, D, I)                                                                       \
-    {                                                                                                          \
-        const __m512i xt = _mm512_add_epi32(x[word_of(I)], _mm512_set1_epi32((int)kT[I]));                     \
-        const __m512i f = _mm512_ternarylogic_epi32(B, C, D, IMM);                                             \
-        /* (A + xt) does not wait for the previous step: the chain is f -> add -> rotate -> add */              \
-        A = _mm512_add_epi32(B, _mm512_rolv_epi32(_mm512_add_epi32(_mm512_add_epi32(A, xt), f),               \
-                                                 _mm512_set1_epi32(kS[ROUND][(I) & 3])));                      \
-    }
-    for (int i = 16 * ROUND; i < 16 * ROUND + 16; i += 4) {
-        FLACENC_MD5_STEP(a, b, c, d, i)
-        FLACENC_MD5_STEP(d, a, b, c, i + 1)
-        FLACENC_MD5_STEP(c, d, a, b, i + 2)
-        FLACENC_MD5_STEP(b, c, d, a, i + 3)
-    }
-#undef FLACENC_MD5_STEP
+// the 64 steps on sixteen lanes, written out (constant rotations and message words: the compiler keeps the
+// sixteen words and the state in registers); F = b ? c : d, G = d ? b : c, H = b ^ c ^ d, I = c ^ (b | ~d) as
+// truth tables of vpternlogd on (b, c, d).  (A + x + t) does not wait for the previous step: the chain is
+// f -> add -> rotate -> add.
+#define MD5X_STEP(IMM, A, B, C, D, W, T, S)                                                          \
+    A = _mm512_add_epi32(B, _mm512_rol_epi32(                                                         \
+               _mm512_add_epi32(_mm512_add_epi32(A, _mm512_add_epi32(x[W], _mm512_set1_epi32((int)(T)))), \
+                                _mm512_ternarylogic_epi32(B, C, D, IMM)), S));
+__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void md5_64steps(__m512i &a, __m512i &b, __m512i &c, __m512i &d,
+                                                                            const __m512i (&x)[16]) {
+    MD5X_STEP(0xCA, a, b, c, d,  0, 0xd76aa478u,  7)
+    MD5X_STEP(0xCA, d, a, b, c,  1, 0xe8c7b756u, 12)
+    MD5X_STEP(0xCA, c, d, a, b,  2, 0x242070dbu, 17)
+    MD5X_STEP(0xCA, b, c, d, a,  3, 0xc1bdceeeu, 22)
+    MD5X_STEP(0xCA, a, b, c, d,  4, 0xf57c0fafu,  7)
+    MD5X_STEP(0xCA, d, a, b, c,  5, 0x4787c62au, 12)
+    MD5X_STEP(0xCA, c, d, a, b,  6, 0xa8304613u, 17)
+    MD5X_STEP(0xCA, b, c, d, a,  7, 0xfd469501u, 22)
+    MD5X_STEP(0xCA, a, b, c, d,  8, 0x698098d8u,  7)
+    MD5X_STEP(0xCA, d, a, b, c,  9, 0x8b44f7afu, 12)
+    MD5X_STEP(0xCA, c, d, a, b, 10, 0xffff5bb1u, 17)
+    MD5X_STEP(0xCA, b, c, d, a, 11, 0x895cd7beu, 22)
+    MD5X_STEP(0xCA, a, b, c, d, 12, 0x6b901122u,  7)
+    MD5X_STEP(0xCA, d, a, b, c, 13, 0xfd987193u, 12)
+    MD5X_STEP(0xCA, c, d, a, b, 14, 0xa679438eu, 17)
+    MD5X_STEP(0xCA, b, c, d, a, 15, 0x49b40821u, 22)
+    MD5X_STEP(0xE4, a, b, c, d,  1, 0xf61e2562u,  5)
+    MD5X_STEP(0xE4, d, a, b, c,  6, 0xc040b340u,  9)
+    MD5X_STEP(0xE4, c, d, a, b, 11, 0x265e5a51u, 14)
+    MD5X_STEP(0xE4, b, c, d, a,  0, 0xe9b6c7aau, 20)
+    MD5X_STEP(0xE4, a, b, c, d,  5, 0xd62f105du,  5)
+    MD5X_STEP(0xE4, d, a, b, c, 10, 0x02441453u,  9)
+    MD5X_STEP(0xE4, c, d, a, b, 15, 0xd8a1e681u, 14)
+    MD5X_STEP(0xE4, b, c, d, a,  4, 0xe7d3fbc8u, 20)
+    MD5X_STEP(0xE4, a, b, c, d,  9, 0x21e1cde6u,  5)
+    MD5X_STEP(0xE4, d, a, b, c, 14, 0xc33707d6u,  9)
+    MD5X_STEP(0xE4, c, d, a, b,  3, 0xf4d50d87u, 14)
+    MD5X_STEP(0xE4, b, c, d, a,  8, 0x455a14edu, 20)
+    MD5X_STEP(0xE4, a, b, c, d, 13, 0xa9e3e905u,  5)
+    MD5X_STEP(0xE4, d, a, b, c,  2, 0xfcefa3f8u,  9)
+    MD5X_STEP(0xE4, c, d, a, b,  7, 0x676f02d9u, 14)
+    MD5X_STEP(0xE4, b, c, d, a, 12, 0x8d2a4c8au, 20)
+    MD5X_STEP(0x96, a, b, c, d,  5, 0xfffa3942u,  4)
+    MD5X_STEP(0x96, d, a, b, c,  8, 0x8771f681u, 11)
+    MD5X_STEP(0x96, c, d, a, b, 11, 0x6d9d6122u, 16)
+    MD5X_STEP(0x96, b, c, d, a, 14, 0xfde5380cu, 23)
+    MD5X_STEP(0x96, a, b, c, d,  1, 0xa4beea44u,  4)
+    MD5X_STEP(0x96, d, a, b, c,  4, 0x4bdecfa9u, 11)
+    MD5X_STEP(0x96, c, d, a, b,  7, 0xf6bb4b60u, 16)
+    MD5X_STEP(0x96, b, c, d, a, 10, 0xbebfbc70u, 23)
+    MD5X_STEP(0x96, a, b, c, d, 13, 0x289b7ec6u,  4)
+    MD5X_STEP(0x96, d, a, b, c,  0, 0xeaa127fau, 11)
+    MD5X_STEP(0x96, c, d, a, b,  3, 0xd4ef3085u, 16)
+    MD5X_STEP(0x96, b, c, d, a,  6, 0x04881d05u, 23)
+    MD5X_STEP(0x96, a, b, c, d,  9, 0xd9d4d039u,  4)
+    MD5X_STEP(0x96, d, a, b, c, 12, 0xe6db99e5u, 11)
+    MD5X_STEP(0x96, c, d, a, b, 15, 0x1fa27cf8u, 16)
+    MD5X_STEP(0x96, b, c, d, a,  2, 0xc4ac5665u, 23)
+    MD5X_STEP(0x39, a, b, c, d,  0, 0xf4292244u,  6)
+    MD5X_STEP(0x39, d, a, b, c,  7, 0x432aff97u, 10)
+    MD5X_STEP(0x39, c, d, a, b, 14, 0xab9423a7u, 15)
+    MD5X_STEP(0x39, b, c, d, a,  5, 0xfc93a039u, 21)
+    MD5X_STEP(0x39, a, b, c, d, 12, 0x655b59c3u,  6)
+    MD5X_STEP(0x39, d, a, b, c,  3, 0x8f0ccc92u, 10)
+    MD5X_STEP(0x39, c, d, a, b, 10, 0xffeff47du, 15)
+    MD5X_STEP(0x39, b, c, d, a,  1, 0x85845dd1u, 21)
+    MD5X_STEP(0x39, a, b, c, d,  8, 0x6fa87e4fu,  6)
+    MD5X_STEP(0x39, d, a, b, c, 15, 0xfe2ce6e0u, 10)
+    MD5X_STEP(0x39, c, d, a, b,  6, 0xa3014314u, 15)
+    MD5X_STEP(0x39, b, c, d, a, 13, 0x4e0811a1u, 21)
+    MD5X_STEP(0x39, a, b, c, d,  4, 0xf7537e82u,  6)
+    MD5X_STEP(0x39, d, a, b, c, 11, 0xbd3af235u, 10)
+    MD5X_STEP(0x39, c, d, a, b,  2, 0x2ad7d2bbu, 15)
+    MD5X_STEP(0x39, b, c, d, a,  9, 0xeb86d391u, 21)
 }
+#undef MD5X_STEP
 
 __attribute__((target("avx512f,avx512bw,avx512vl"))) void md5_x16_avx512(uint32_t state[4][16], const uint8_t *const ptr[16],
                                                                          size_t nblocks, uint32_t mask) {
@@ -102,6 +147,7 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) void md5_x16_avx512(uint32_
     __m512i C = _mm512_loadu_si512(state[2]), D = _mm512_loadu_si512(state[3]);
     for (size_t blk = 0; blk < nblocks; blk++) {
         __m512i x[16];
+#pragma GCC unroll 16
         for (int l = 0; l < 16; l++) {
             x[l] = _mm512_loadu_si512(p[l]);
             _mm_prefetch(reinterpret_cast<const char *>(p[l]) + 1024, _MM_HINT_T0);   // sixteen sequential readers
@@ -109,10 +155,7 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) void md5_x16_avx512(uint32_
         }
         transpose16(x);
         __m512i a = A, b = B, c = C, d = D;
-        round16<0, 0xCA>(a, b, c, d, x);   // F = b ? c : d
-        round16<1, 0xE4>(a, b, c, d, x);   // G = d ? b : c
-        round16<2, 0x96>(a, b, c, d, x);   // H = b ^ c ^ d
-        round16<3, 0x39>(a, b, c, d, x);   // I = c ^ (b | ~d)
+        md5_64steps(a, b, c, d, x);
         A = _mm512_add_epi32(A, a);
         B = _mm512_add_epi32(B, b);
         C = _mm512_add_epi32(C, c);
