@@ -105,3 +105,22 @@ def test_batch_front_end_matches_oracle():
         for s, o in zip(streams, outs):
             rc, ref, _ = orc.encode_stream(orc.options("default"), 44100, 16, 2, s, total_known=True)
             assert rc == 0 and o == ref
+
+
+def test_many_writers_on_the_shared_md5_engines():
+    """More concurrent streams than one engine has lanes, 24-bit (3-byte samples: runs that are no multiple of
+    the 64-byte MD5 block), ragged lengths, sleeping waits: every finished stream -- STREAMINFO MD5 included --
+    must be the oracle's."""
+    import hashlib
+
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    streams = [synth_fast(1300 + i, 2, 24, 4096 * (2 + (7 * i) % 11) + 37 * i + (i % 3)) for i in range(40)]
+    streams = [s[: s.size - s.size % 2] for s in streams]
+    be = BatchEncoder(Options.best().batch_frames(8), threads=40)
+    outs = be.encode(streams, 48000, 24, 2)
+    for s, o in zip(streams, outs):
+        rc, ref, _ = orc.encode_stream(orc.options("best"), 48000, 24, 2, s, total_known=True)
+        assert rc == 0 and o == ref
+        le3 = s.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+        assert o[26:42] == hashlib.md5(le3).digest()      # STREAMINFO: 4 + 4 + 18 bytes in front of the MD5
