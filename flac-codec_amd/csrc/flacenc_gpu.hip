@@ -89,6 +89,11 @@ struct flacgpu_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_layout = nullptr;
     bool two_ranges = false;         // FLACGPU_TUNE_TWO_RANGES
+    // flacgpu_encode_packed_async_host: k_frame64 writes the batch's frames straight into this pinned host
+    // buffer (no d_packed, no download) when every frame of the batch takes it; out_in_host says it did
+    uint8_t *host_out = nullptr;
+    size_t host_out_cap = 0;
+    bool out_in_host = false;
     bool blocking_wait = false;      // FLACGPU_TUNE_BLOCKING_WAIT
     int lag_split = 4;               // FLACGPU_TUNE_LAG_SPLIT
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
@@ -596,6 +601,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     }
     Params p;
     fill_params(c, n_frames, last_len, p);
+    c->host_out = nullptr;   // a new batch: frames go to d_packed unless flacgpu_encode_packed_async_host says otherwise
+    c->out_in_host = false;
 
     int evi = 0;
     for (auto &u : c->ev_used) u = false;
@@ -879,7 +886,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     PackParams q;
     q.first_frame_number = first_frame_number;
     q.sample_rate = sample_rate;
-    q.out_words = c->d_packed;
+    q.out_words = c->d_packed;   // (k_layout does not look at it; replaced below for host output)
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
@@ -907,6 +914,10 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     pf.fcount = n_fast;
     pg.f0 = n_fast;
     pg.fcount = p.n_frames - n_fast;
+    // host output: k_frame64 only ever stores (dwords inside a frame, bytes at its ends), so it can write
+    // over PCIe into pinned memory; the generic packer builds its frames with atomic ORs and cannot
+    c->out_in_host = c->host_out && pf.fcount && pg.fcount == 0 && c->host_out_cap >= c->packed_cap;
+    if (c->out_in_host) q.out_words = reinterpret_cast<uint32_t *>(c->host_out);
     if (pg.fcount) launch_zero(q, p.n_frames, st);
     if (c->timing) (void)hipEventRecord(ev[1], st);
     if (pf.fcount) launch_frame64(pf, q, B, pf.fcount, (size_t)fbw * sizeof(int32_t), st);
@@ -1078,6 +1089,10 @@ int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *off
         g_last_error = "output buffer too small";
         return FLACGPU_ERR_BUFFER_TOO_SMALL;
     }
+    if (c->out_in_host) {   // the batch was assembled into the caller's host buffer (ctx_sync above: complete)
+        if (out != c->host_out) memcpy(out, c->host_out, bytes);
+        return FLACGPU_OK;
+    }
     if (int rc = copy_sync(c, out, c->d_packed, bytes, hipMemcpyDeviceToHost)) return rc;
     return FLACGPU_OK;
 }
@@ -1131,6 +1146,8 @@ int flacgpu_pack_plans(flacgpu_ctx *c, const int32_t *pcm, uint32_t n_frames, ui
     c->direct_src = nullptr;
     c->packed_valid = false;
     HIP_TRY(hipStreamSynchronize(st));   // the host arrays may go away
+    c->host_out = nullptr;
+    c->out_in_host = false;
     return pack_impl(c, first_frame_number, sample_rate, st, nullptr);
 }
 
@@ -1424,9 +1441,18 @@ static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal 
     return FLACGPU_OK;
 }
 
+size_t flacgpu_packed_cap(const flacgpu_ctx *c) { return c ? (size_t)c->packed_cap + 64 : 0; }
+
 int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
                                 uint32_t n_frames, uint32_t last_len, uint64_t first_frame_number,
                                 uint32_t sample_rate) {
+    return flacgpu_encode_packed_async_host(c, pcm_le, bytes_per_sample, n_frames, last_len, first_frame_number,
+                                            sample_rate, nullptr, 0);
+}
+
+int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                     uint32_t n_frames, uint32_t last_len, uint64_t first_frame_number,
+                                     uint32_t sample_rate, uint8_t *out_host, size_t out_cap) {
     if (!c || !pcm_le || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
         last_len > c->opts.block_size ||
         !(bytes_per_sample == 4 || (bytes_per_sample == (c->bps + 7) / 8 &&
@@ -1444,7 +1470,12 @@ int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t 
         return rc;
     // the frame sizes leave the device as soon as k_layout has run (second stream), so that the host
     // can size the copy of the bytes while k_frame64 is still assembling them
+    c->host_out = (reinterpret_cast<uintptr_t>(out_host) & 3u) ? nullptr : out_host;
+    c->host_out_cap = out_cap;
     if (int rc = pack_impl(c, first_frame_number, sample_rate, st, c->ev_layout)) return rc;
+    // frames written straight to the host buffer: they are there when the stream has drained
+    if (c->out_in_host)
+        if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, st)) return rc;
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_layout, 0));
     HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
                            hipMemcpyDeviceToHost, c->aux_stream));
@@ -1467,6 +1498,8 @@ int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *tot
             c->ties_checked = true;   // the common case: nothing to re-decide, nothing to wait for
         } else {                      // order ties: host re-decision, then the sizes again
             if (int rc = resolve_order_ties(c)) return rc;
+            if (c->out_in_host)   // assembled again, into the host buffer again
+                if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, ctx_stream(c))) return rc;
             if (int rc = copy_sync(c, c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)c->last_frames + 1),
                                    hipMemcpyDeviceToHost))
                 return rc;
@@ -1488,6 +1521,14 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
     if (cap < bytes) {
         g_last_error = "output buffer too small";
         return FLACGPU_ERR_BUFFER_TOO_SMALL;
+    }
+    if (c->out_in_host) {   // k_frame64 wrote them there; the event was recorded behind it
+        if (out != c->host_out) {
+            if (int rc = wait_waitable(c, c->ev_bytes, c->sig_bytes)) return rc;
+            memcpy(out, c->host_out, bytes);
+        }
+        c->bytes_pending = true;
+        return FLACGPU_OK;
     }
     HIP_TRY(hipMemcpyAsync(out, c->d_packed, bytes, hipMemcpyDeviceToHost, c->own_stream));
     if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, c->own_stream)) return rc;
@@ -1565,6 +1606,10 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     if (!c || !c->packed_valid || !result) {
         g_last_error = "flacgpu_verify_device: nothing packed";
         return FLACGPU_ERR_INVALID_ARG;
+    }
+    if (c->out_in_host) {
+        g_last_error = "flacgpu_verify_device: the batch was assembled into the caller's host buffer";
+        return FLACGPU_ERR_UNSUPPORTED;
     }
     CTX_GUARD(c);
     if (int rc = resolve_order_ties(c)) return rc;

@@ -791,8 +791,10 @@ struct flacenc_writer {
                 ticket = md5_worker.pushed;
             }
             const double t1 = now_ms();
-            int rc = flacgpu_encode_packed_async(lane->gpu, lane->pin_in, upload_width, usable, ll, frame_number,
-                                                 si.sample_rate);
+            // the frames come back by themselves: k_frame64 writes them into the lane's pinned buffer
+            if (int rc = lane->reserve_out(flacgpu_packed_cap(lane->gpu))) return rc;
+            int rc = flacgpu_encode_packed_async_host(lane->gpu, lane->pin_in, upload_width, usable, ll, frame_number,
+                                                      si.sample_rate, lane->pin_out, lane->pin_out_cap);
             stats.gpu_ms += now_ms() - t1;
             if (rc) return map_gpu_error(rc);
             inflight.push_back({lane, usable, ll, ticket});

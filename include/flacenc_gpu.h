@@ -262,6 +262,16 @@ int flacgpu_encode_packed_async(flacgpu_ctx *ctx, const uint8_t *pcm_le, uint32_
                                 uint32_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number,
                                 uint32_t sample_rate);
 int flacgpu_frames_ready(flacgpu_ctx *ctx, const uint64_t **offsets, uint64_t *total);
+/* As flacgpu_encode_packed_async, with the frames assembled STRAIGHT INTO `out_host` (pinned memory from
+ * flacgpu_host_alloc, at least flacgpu_packed_cap(ctx) bytes, 4-byte aligned): k_frame64 only stores -- dwords
+ * inside a frame, bytes at its ends -- so it writes over PCIe while it works and no download follows.  Taken
+ * when every frame of the batch is assembled by k_frame64 (whole blocks of a wave block length); otherwise
+ * the frames stay in device memory as usual.  flacgpu_fetch_frames_async(out_host) then has nothing to copy;
+ * flacgpu_wait returns when the frames are in `out_host`. */
+int flacgpu_encode_packed_async_host(flacgpu_ctx *ctx, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                     uint32_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number,
+                                     uint32_t sample_rate, uint8_t *out_host, size_t out_cap);
+size_t flacgpu_packed_cap(const flacgpu_ctx *ctx);   /* bytes a batch of max_frames frames can need */
 int flacgpu_fetch_frames_async(flacgpu_ctx *ctx, uint8_t *out, size_t cap);
 int flacgpu_wait(flacgpu_ctx *ctx);
 
