@@ -259,7 +259,8 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                            "best_Msamples/s": round(n_streams * per.size / min(times) / 1e6, 1),
                            "note": "median of 5 calls of flacenc_encode_many (C++ front end: one writer per "
                                    "worker thread, pooled lanes, the streams' MD5 chains on the shared 16-lane "
-                                   "AVX-512 engines, waits that sleep); host PCM -> .flac bytes in caller buffers"}
+                                   "AVX-512 engines, waits that sleep, frames written by k_frame64 straight into pinned host memory); host PCM "
+                                   "-> .flac bytes in caller buffers"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
     batch = pcm[: 1024 * BLOCK * C]

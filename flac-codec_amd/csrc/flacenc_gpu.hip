@@ -40,8 +40,9 @@
 
 #include <algorithm>
 #include <cmath>
-#include <condition_variable>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -110,13 +111,7 @@ struct flacgpu_ctx {
     // asynchronous host path (flacgpu_encode_packed_async ...)
     uint64_t *h_off = nullptr;          // pinned: byte offsets of the frames of the batch in flight
     hipEvent_t ev_sizes = nullptr, ev_bytes = nullptr, ev_null = nullptr;
-    // FLACGPU_TUNE_BLOCKING_WAIT: the waits for ev_sizes / ev_bytes sleep on a condition variable that a host
-    // function queued behind the event wakes (hipEventSynchronize spins, also with hipEventBlockingSync)
-    struct HostSignal {
-        std::mutex mu;
-        std::condition_variable cv;
-        uint64_t posted = 0, fired = 0;
-    } sig_sizes, sig_bytes;
+    struct HostSignal {} sig_sizes, sig_bytes;   // (placeholders of the event pairs' call sites)
     bool sizes_pending = false, bytes_pending = false;
     // last call
     uint32_t last_frames = 0, last_len = 0;
@@ -1411,31 +1406,23 @@ int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_samp
     return c && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample) ? 1 : 0;
 }
 
-static void host_signal_fire(void *user) {
-    auto *sg = static_cast<flacgpu_ctx::HostSignal *>(user);
-    {
-        std::lock_guard<std::mutex> lock(sg->mu);
-        sg->fired++;
-    }
-    sg->cv.notify_all();
-}
-// record `ev` on `st`; in blocking-wait mode also queue the wake-up behind it
-static int record_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &sg, hipStream_t st) {
+// record `ev` on `st` (the waits below are for it)
+static int record_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &, hipStream_t st) {
+    (void)c;
     HIP_TRY(hipEventRecord(ev, st));
-    if (c->blocking_wait) {
-        {
-            std::lock_guard<std::mutex> lock(sg.mu);
-            sg.posted++;
-        }
-        HIP_TRY(hipLaunchHostFunc(st, host_signal_fire, &sg));
-    }
     return FLACGPU_OK;
 }
-static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &sg) {
+// FLACGPU_TUNE_BLOCKING_WAIT: the thread sleeps between looks at the event instead of spinning in
+// hipEventSynchronize (which spins also with hipEventBlockingSync; a hipLaunchHostFunc wake-up keeps runtime
+// helper threads busy instead: 0.3 CPU-seconds per 40 ms call with 64 writers)
+static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &) {
     if (c->blocking_wait) {
-        std::unique_lock<std::mutex> lock(sg.mu);
-        sg.cv.wait(lock, [&] { return sg.fired >= sg.posted; });
-        return FLACGPU_OK;
+        for (unsigned spins = 0;; spins++) {
+            const hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess) return FLACGPU_OK;
+            if (e != hipErrorNotReady) HIP_TRY(e);
+            std::this_thread::sleep_for(std::chrono::microseconds(spins < 8 ? 50 : 200));
+        }
     }
     HIP_TRY(hipEventSynchronize(ev));
     return FLACGPU_OK;

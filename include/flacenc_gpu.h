@@ -206,10 +206,10 @@ enum {
      * a context that has the GPU to itself) or 2 (fewer instructions; best when several contexts
      * keep the SIMDs busy).  Results are identical. */
     FLACGPU_TUNE_LAG_SPLIT = 2,
-    /* 1: flacgpu_frames_ready / flacgpu_fetch_frames_async / flacgpu_wait sleep on a condition variable that
-     * a host function queued behind their event wakes, instead of spinning in hipEventSynchronize.  For
-     * processes with more waiting threads than CPUs (many concurrent writers): a spinning waiter burns the
-     * CPU time the others -- and the MD5 engines -- need.  0 (default) spins (lowest latency). */
+    /* 1: flacgpu_frames_ready / flacgpu_fetch_frames_async / flacgpu_wait sleep between looks at their
+     * event (50-200 us) instead of spinning in hipEventSynchronize.  For processes with more waiting threads
+     * than CPUs (many concurrent writers): a spinning waiter burns the CPU time the others -- and the MD5
+     * engines -- need.  0 (default) spins (lowest latency). */
     FLACGPU_TUNE_BLOCKING_WAIT = 3
 };
 int flacgpu_set_tuning(flacgpu_ctx *ctx, int key, int value);

@@ -26,6 +26,18 @@ for n_streams, threads, batch, depth in CASES:
     for _ in range(7):
         t = time.perf_counter(); be.encode(streams, 48000, 24, 2, copy=False); ts.append(time.perf_counter() - t)
     th1, c1 = throttled(), time.process_time()
+    if os.environ.get("PROBE_THREADS"):
+        import glob, collections
+        agg = collections.Counter()
+        for st in glob.glob("/proc/self/task/*/stat"):
+            try:
+                f = open(st).read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                agg[comm] += (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK")
+            except Exception:
+                pass
+        print("  cpu seconds of the LIVE threads by name (whole process life):", dict(agg.most_common(8)))
     print(f"  cpu s per call {(c1 - c0) / 7:.3f}; throttled periods +{th1.get('nr_throttled', 0) - th0.get('nr_throttled', 0)}, "
           f"throttled ms +{(th1.get('throttled_usec', 0) - th0.get('throttled_usec', 0)) / 1e3:.0f}")
     j = be.last_jobs
