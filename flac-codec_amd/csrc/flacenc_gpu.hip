@@ -626,7 +626,9 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->direct_src = direct ? d_pcm : nullptr;
     if (direct) p.inter = d_pcm;
     // K0 (+ OR of every candidate's samples -> wasted bits)
-    const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && last_len == B;
+    // (one channel: interleaved and planar are the same bytes -- no copy either)
+    const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
+                               last_len == B && !getenv("FLACGPU_NO_DIRECT");
     if (!direct) begin(0);
     bool have_orbits = direct;
     if (direct) {
@@ -1616,8 +1618,9 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     if (int rc = ensure_planar(c)) return rc;
     if (int rc = ctx_sync(c)) return rc;
     HIP_TRY(hipMemsetAsync(c->d_verify, 0, sizeof(uint32_t) * (4 + (size_t)p.n_frames), st));
-    // compare against the planar PCM the analysis consumed, when it is the context's own copy
-    const int32_t *expect = (p.planar == c->d_planar && p.ldb == c->ldb) ? c->d_planar : nullptr;
+    // compare against the planar PCM the analysis consumed: the context's copy, or the rows it read in place
+    // (planar / one-channel input: the caller's buffer is still valid here, include/flacenc_gpu.h)
+    const int32_t *expect = (p.ldb == c->ldb) ? p.planar : nullptr;
     Params pd = p;
     pd.ldb = c->ldb;
     (void)hipEventRecord(c->ev[0], st);
