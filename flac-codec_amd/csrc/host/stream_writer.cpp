@@ -791,8 +791,11 @@ struct flacenc_writer {
                 ticket = md5_worker.pushed;
             }
             const double t1 = now_ms();
-            // the frames come back by themselves: k_frame64 writes them into the lane's pinned buffer
-            if (int rc = lane->reserve_out(flacgpu_packed_cap(lane->gpu))) return rc;
+            // the frames come back by themselves: k_frame64 writes them into the lane's pinned buffer (which must
+            // then hold the worst case of a batch -- not pinned for shapes where that is hundreds of megabytes)
+            const size_t worst = flacgpu_packed_cap(lane->gpu);
+            if (worst <= (size_t(64) << 20))
+                if (int rc = lane->reserve_out(worst)) return rc;
             int rc = flacgpu_encode_packed_async_host(lane->gpu, lane->pin_in, upload_width, usable, ll, frame_number,
                                                       si.sample_rate, lane->pin_out, lane->pin_out_cap);
             stats.gpu_ms += now_ms() - t1;
