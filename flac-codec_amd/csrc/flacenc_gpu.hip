@@ -111,7 +111,6 @@ struct flacgpu_ctx {
     // asynchronous host path (flacgpu_encode_packed_async ...)
     uint64_t *h_off = nullptr;          // pinned: byte offsets of the frames of the batch in flight
     hipEvent_t ev_sizes = nullptr, ev_bytes = nullptr, ev_null = nullptr;
-    struct HostSignal {} sig_sizes, sig_bytes;   // (placeholders of the event pairs' call sites)
     bool sizes_pending = false, bytes_pending = false;
     // last call
     uint32_t last_frames = 0, last_len = 0;
@@ -1409,15 +1408,14 @@ int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_samp
 }
 
 // record `ev` on `st` (the waits below are for it)
-static int record_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &, hipStream_t st) {
-    (void)c;
+static int record_waitable(flacgpu_ctx *, hipEvent_t ev, hipStream_t st) {
     HIP_TRY(hipEventRecord(ev, st));
     return FLACGPU_OK;
 }
 // FLACGPU_TUNE_BLOCKING_WAIT: the thread sleeps between looks at the event instead of spinning in
 // hipEventSynchronize (which spins also with hipEventBlockingSync; a hipLaunchHostFunc wake-up keeps runtime
 // helper threads busy instead: 0.3 CPU-seconds per 40 ms call with 64 writers)
-static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev, flacgpu_ctx::HostSignal &) {
+static int wait_waitable(flacgpu_ctx *c, hipEvent_t ev) {
     if (c->blocking_wait) {
         for (unsigned spins = 0;; spins++) {
             const hipError_t e = hipEventQuery(ev);
@@ -1464,12 +1462,12 @@ int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint
     if (int rc = pack_impl(c, first_frame_number, sample_rate, st, c->ev_layout)) return rc;
     // frames written straight to the host buffer: they are there when the stream has drained
     if (c->out_in_host)
-        if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, st)) return rc;
+        if (int rc = record_waitable(c, c->ev_bytes, st)) return rc;
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_layout, 0));
     HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
                            hipMemcpyDeviceToHost, c->aux_stream));
     HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, c->aux_stream));
-    if (int rc = record_waitable(c, c->ev_sizes, c->sig_sizes, c->aux_stream)) return rc;
+    if (int rc = record_waitable(c, c->ev_sizes, c->aux_stream)) return rc;
     c->sizes_pending = true;
     c->bytes_pending = false;
     return FLACGPU_OK;
@@ -1481,14 +1479,14 @@ int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *tot
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
-    if (int rc = wait_waitable(c, c->ev_sizes, c->sig_sizes)) return rc;
+    if (int rc = wait_waitable(c, c->ev_sizes)) return rc;
     if (!c->ties_checked) {
         if (c->h_stats[1] == 0) {
             c->ties_checked = true;   // the common case: nothing to re-decide, nothing to wait for
         } else {                      // order ties: host re-decision, then the sizes again
             if (int rc = resolve_order_ties(c)) return rc;
             if (c->out_in_host)   // assembled again, into the host buffer again
-                if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, ctx_stream(c))) return rc;
+                if (int rc = record_waitable(c, c->ev_bytes, ctx_stream(c))) return rc;
             if (int rc = copy_sync(c, c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)c->last_frames + 1),
                                    hipMemcpyDeviceToHost))
                 return rc;
@@ -1505,7 +1503,7 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
-    if (int rc = wait_waitable(c, c->ev_sizes, c->sig_sizes)) return rc;
+    if (int rc = wait_waitable(c, c->ev_sizes)) return rc;
     const uint64_t bytes = c->h_off[c->last_frames];
     if (cap < bytes) {
         g_last_error = "output buffer too small";
@@ -1513,14 +1511,14 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
     }
     if (c->out_in_host) {   // k_frame64 wrote them there; the event was recorded behind it
         if (out != c->host_out) {
-            if (int rc = wait_waitable(c, c->ev_bytes, c->sig_bytes)) return rc;
+            if (int rc = wait_waitable(c, c->ev_bytes)) return rc;
             memcpy(out, c->host_out, bytes);
         }
         c->bytes_pending = true;
         return FLACGPU_OK;
     }
     HIP_TRY(hipMemcpyAsync(out, c->d_packed, bytes, hipMemcpyDeviceToHost, c->own_stream));
-    if (int rc = record_waitable(c, c->ev_bytes, c->sig_bytes, c->own_stream)) return rc;
+    if (int rc = record_waitable(c, c->ev_bytes, c->own_stream)) return rc;
     c->bytes_pending = true;
     return FLACGPU_OK;
 }
@@ -1529,7 +1527,7 @@ int flacgpu_wait(flacgpu_ctx *c) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     CTX_GUARD(c);
     if (c->bytes_pending) {
-        if (int rc = wait_waitable(c, c->ev_bytes, c->sig_bytes)) return rc;
+        if (int rc = wait_waitable(c, c->ev_bytes)) return rc;
         c->bytes_pending = false;
         c->sizes_pending = false;
         return FLACGPU_OK;
