@@ -13,7 +13,9 @@ namespace flacgpu_k {
 void launch_cand64_direct(const Params &p, uint32_t blocks, hipStream_t st) {
     static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
     const uint32_t grid = blocks < cap ? blocks : cap;   // default: two workgroups per CU
-    if (p.max_lpc_order > 16)
+    if (p.max_lpc_order == 0)   // no LPC: no k_autocorr4 / k_lpc before this kernel, it derives the candidate info itself
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
+    else if (p.max_lpc_order > 16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, true, true>), dim3(grid), dim3(WG), 0, st, p);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);

@@ -529,7 +529,7 @@ static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
 
 // packed_bytes != 0: the PCM sits in c->d_in as interleaved little-endian samples of that many bytes
 // Whether a batch of interleaved i32 PCM can be analysed and assembled in place (Params::inter): stereo with
-// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks, LPC on, the exhaustive search
+// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks, the exhaustive search
 // (k_stereo_stats reads planar rows), and every stage on its wave kernel -- none of the knobs that select an
 // older or generic kernel (they read Params::planar).
 static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
@@ -539,7 +539,7 @@ static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last
                             getenv("FLACGPU_NO_FRAME64");
     const uint32_t B = p.block_size;
     return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B && p.exhaustive &&
-           p.max_lpc_order > 0 && p.max_po <= 6 && p.ac_split != 2 &&
+           p.max_po <= 6 && p.ac_split != 2 &&
            (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
 }
 

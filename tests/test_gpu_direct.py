@@ -95,6 +95,18 @@ def test_constant_silent_and_noise(monkeypatch):
     check(np.full(B * 2 * 2, -(1 << 23), dtype=np.int32), 24, monkeypatch)   # DC at the negative rail
 
 
+def test_without_lpc(monkeypatch):
+    """No LPC: no autocorrelation kernel to take the ORs from -- the candidate waves OR their own samples."""
+    check(synth_fast(950, 2, 16, B * 7), 16, monkeypatch, max_lpc=0, rate=44100)
+    x = synth_fast(951, 2, 16, B * 5).reshape(-1, 2).astype(np.int64)
+    x[:, 0] <<= 4
+    x[:, 1] <<= 2                                                  # L: 4, R: 2, mid: 1 (or more), side: 2
+    x[B:2 * B] = 0
+    x[2 * B:3 * B, 1] = 0
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0)
+    check(synth_fast(952, 2, 24, B * 3), 24, monkeypatch, max_lpc=0, mid_side=False)
+
+
 def test_device_buffer_input(monkeypatch):
     """The bench's entry point: PCM already in HBM, owned by the caller (a torch tensor)."""
     import torch
