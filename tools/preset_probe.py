@@ -1,0 +1,25 @@
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch
+from _pcm import synth_fast
+from flac_codec_amd.gpu import GpuAnalyzer
+for name, B, po, lpc, ms, ex in (("fast", 1152, 3, 0, False, False), ("default", 4096, 5, 8, True, True), ("best", 4096, 6, 12, True, True)):
+    F = 8192 * 4096 // B
+    base = synth_fast(77, 2, 16, B * 512)
+    pcm = np.tile(base, (F + 511) // 512)[: F * B * 2]
+    d = torch.from_numpy(pcm).cuda()
+    ans = [GpuAnalyzer(B, po, lpc, ms, ex, 2, 0.5, 16, 2, max_frames=F) for _ in range(4)]
+    ss = [torch.cuda.Stream() for _ in ans]
+    for i in range(16):
+        ans[i % 4].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % 4].cuda_stream)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(100):
+        ans[i % 4].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % 4].cuda_stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 100
+    ans[0].set_timing(True)
+    ans[0].analyze_device(d.data_ptr(), F, B); ans[0].pack_device(0, 44100); torch.cuda.synchronize()
+    k = ans[0].kernel_ms()
+    print(f"{name}: {dt*1e3:.3f} ms per {F} frames of {B} = {F*B*2/dt/1e9:.1f} Gsamples/s; kernels {({a: round(b, 3) for a, b in k.items()})}")
+    for a in ans: a.close()
