@@ -85,6 +85,8 @@ struct flacgpu_ctx {
     uint32_t last_rate = 0;
     uint32_t *h_stats = nullptr;    // pinned copy of the 4 counters (asynchronous host path)
     int32_t *d_big = nullptr;       // blocks > LDS_BLOCK_LIMIT: per-workgroup arrays of the generic kernels
+    unsigned long long *d_abs = nullptr;   // stereo, fast channel choice: K0's sums of |l|, |r|, |mid|, |side| per frame
+    bool abs_valid = false;         // K0 of the batch in hand filled d_abs (k_candinfo then makes the choice)
     int32_t *d_decoded = nullptr;   // [F][C][ldb] PCM decoded back from the packed frames (lazy)
     uint32_t *d_verify = nullptr;   // [4] verify counters
     hipStream_t aux_stream = nullptr;
@@ -239,8 +241,10 @@ bool launch_k0(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_fram
     const uint32_t B = c->opts.block_size;
     const dim3 grid(std::max<uint32_t>(1u, (B + WG * 8 - 1) / (WG * 8)), fcount);  // 8 samples per lane
     if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->channels == 2) {
+        unsigned long long *abs = (c->d_abs && c->ncand == 4) ? c->d_abs : nullptr;   // (zeroed by the caller)
         hipLaunchKernelGGL(k_deinterleave2, grid, dim3(WG), 0, st, (const int2 *)d_pcm, c->d_planar, B, c->ldb,
-                           n_frames, last_len, c->d_orbits, c->ncand, f0);
+                           n_frames, last_len, c->d_orbits, c->ncand, f0, abs);
+        c->abs_valid = abs != nullptr;
         return true;
     }
     if (layout == FLACGPU_LAYOUT_INTERLEAVED && c->ncand == c->channels) {
@@ -267,14 +271,16 @@ void launch_k0_packed_c(flacgpu_ctx *c, uint32_t bytes, const dim3 &grid, uint32
                         uint32_t f0, hipStream_t st) {
     const uint32_t *in = reinterpret_cast<const uint32_t *>(c->d_in);
     const uint32_t B = c->opts.block_size;
+    unsigned long long *abs = (C == 2 && c->d_abs && c->ncand == 4) ? c->d_abs : nullptr;   // (zeroed by the caller)
     switch (bytes) {
     case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 1>), grid, dim3(WG), 0, st, in, c->d_planar, B,
-                               c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+                               c->ldb, n_frames, last_len, c->d_orbits, f0, abs); break;
     case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 2>), grid, dim3(WG), 0, st, in, c->d_planar, B,
-                               c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+                               c->ldb, n_frames, last_len, c->d_orbits, f0, abs); break;
     default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_deinterleave_packed<C, 3>), grid, dim3(WG), 0, st, in, c->d_planar, B,
-                                c->ldb, n_frames, last_len, c->d_orbits, f0); break;
+                                c->ldb, n_frames, last_len, c->d_orbits, f0, abs); break;
     }
+    c->abs_valid = abs != nullptr;
 }
 void launch_k0_packed(flacgpu_ctx *c, uint32_t bytes, uint32_t n_frames, uint32_t last_len, hipStream_t st) {
     const uint32_t B = c->opts.block_size;
@@ -411,6 +417,7 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_frame_off, F + 1);
     if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
     ALLOC(c->d_ties, F * NC);
+    if (c->stereo4 && !o->exhaustive_channel_correlation) ALLOC(c->d_abs, F * 4);
     if (const char *e = getenv("FLACGPU_TIE_BAND")) c->tie_band = atof(e);         // test knobs
     if (const char *e = getenv("FLACGPU_TIE_PERTURB")) c->tie_perturb = atof(e);
 #undef ALLOC
@@ -446,6 +453,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     if (c->h_off) (void)hipHostFree(c->h_off);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     (void)hipFree(c->d_ties);
+    (void)hipFree(c->d_abs);
     if (c->ev_sizes) (void)hipEventDestroy(c->ev_sizes);
     if (c->ev_bytes) (void)hipEventDestroy(c->ev_bytes);
     if (c->ev_null) (void)hipEventDestroy(c->ev_null);
@@ -624,6 +632,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->planar_valid = !direct;
     c->direct_src = direct ? d_pcm : nullptr;
     if (direct) p.inter = d_pcm;
+    c->abs_valid = false;
+    if (c->d_abs) HIP_TRY(hipMemsetAsync(c->d_abs, 0, sizeof(unsigned long long) * 4 * n_frames, st));
     // K0 (+ OR of every candidate's samples -> wasted bits)
     // (one channel: interleaved and planar are the same bytes -- no copy either)
     const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
@@ -642,11 +652,13 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     if (!have_orbits)
         launch_orbits(p, c->d_orbits, st);
     const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
-    if (c->stereo4 && !p.exhaustive) {
+    if (c->stereo4 && !p.exhaustive && !c->abs_valid) {   // (K0 summed the magnitudes on the way otherwise)
         begin(1);
         hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
     }
-    if (!direct) hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits);
+    if (!direct)
+        hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits,
+                           c->abs_valid ? c->d_abs : nullptr);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
     // block sizes, a short last frame, candidates wider than 25 bits) the generic LDS ones
     const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
@@ -1031,7 +1043,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         if (!planar_direct) have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, r.f0, r.fcount, st);
         if (!have_orbits) launch_orbits(r, c->d_orbits, st);
         if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats, dim3(r.fcount), dim3(WG), 0, st, r);
-        hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits);
+        hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits, (const unsigned long long *)nullptr);
         if (lpc) {
             dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
             launch_lpc(r, (ncb + 63) / 64, st);
