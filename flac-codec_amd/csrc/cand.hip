@@ -15,8 +15,7 @@ bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
     // persistent variant with LDS prefetch: 4096-sample blocks, order <= 16, enough groups to go round
     static const bool no_persist = getenv("FLACGPU_NO_PERSIST") != nullptr;
     if (p.inter) {   // interleaved stereo input read in place: persistent kernels only (cand_direct.hip)
-        launch_cand64_direct(p, blocks, st);
-        return true;
+        return launch_cand64_direct(p, B, blocks, st);
     }
     if (!no_persist && B == FN && p.max_lpc_order > 16) {
         static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;

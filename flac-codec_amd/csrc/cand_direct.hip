@@ -1,5 +1,6 @@
-// cand_direct.hip -- the DIRECT-input instantiations of k_cand64p (4096-sample stereo frames read from the
-// caller's interleaved PCM, Params::inter); a translation unit of its own only to compile beside cand.hip.
+// cand_direct.hip -- the DIRECT-input instantiations of the persistent candidate kernel k_cand64p: 4096-sample stereo
+// frames read from the caller's interleaved PCM (Params::inter), channel choice included; the SELF variant for
+// streams without LPC.  A translation unit of its own only to compile beside cand.hip.
 #include "kernels/types.h"
 
 #include <stdlib.h>
@@ -10,14 +11,19 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-void launch_cand64_direct(const Params &p, uint32_t blocks, hipStream_t st) {
-    static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
-    const uint32_t grid = blocks < cap ? blocks : cap;   // default: two workgroups per CU
-    if (p.max_lpc_order == 0)   // no LPC: no k_autocorr4 / k_lpc before this kernel, it derives the candidate info itself
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
-    else if (p.max_lpc_order > 16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, true, true>), dim3(grid), dim3(WG), 0, st, p);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);
+bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+    const bool lpc = p.max_lpc_order > 0;
+    if (B == FN) {
+        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
+        const uint32_t grid = blocks < cap ? blocks : cap;   // default: two workgroups per CU
+        if (!lpc)   // no k_autocorr4 / k_lpc before this kernel: it derives the candidate info itself
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
+        else if (p.max_lpc_order > 16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, true, true>), dim3(grid), dim3(WG), 0, st, p);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);
+        return true;
+    }
+    return false;
 }
 }  // namespace flacgpu_k

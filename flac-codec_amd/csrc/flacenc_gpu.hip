@@ -537,16 +537,17 @@ static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
 
 // packed_bytes != 0: the PCM sits in c->d_in as interleaved little-endian samples of that many bytes
 // Whether a batch of interleaved i32 PCM can be analysed and assembled in place (Params::inter): stereo with
-// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks, the exhaustive search
-// (k_stereo_stats reads planar rows), and every stage on its wave kernel -- none of the knobs that select an
-// older or generic kernel (they read Params::planar).
+// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks (the shorter wave block lengths were
+// tried: their non-persistent candidate kernel reads the interleaved frame four times, 0.114 -> 0.172 ms for
+// 1152-sample blocks, more than the split pass costs), and every stage on its wave kernel -- none of the knobs
+// that select an older or generic kernel (they read Params::planar).
 static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
     const bool off = getenv("FLACGPU_NO_DIRECT") || getenv("FLACGPU_NO_FAST") || getenv("FLACGPU_NO_W64") ||
                             getenv("FLACGPU_NO_PERSIST") || getenv("FLACGPU_NO_AC3") || getenv("FLACGPU_AC_PRIVATE") ||
                             getenv("FLACGPU_EXPERIMENT_MFMA_AC") || getenv("FLACGPU_NO_FUSED_PACK") ||
                             getenv("FLACGPU_NO_FRAME64");
     const uint32_t B = p.block_size;
-    return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B && p.exhaustive &&
+    return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B &&
            p.max_po <= 6 && p.ac_split != 2 &&
            (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
 }
@@ -654,7 +655,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
     if (c->stereo4 && !p.exhaustive && !c->abs_valid) {   // (K0 summed the magnitudes on the way otherwise)
         begin(1);
-        hipLaunchKernelGGL(k_stereo_stats, dim3(n_frames), dim3(WG), 0, st, p);
+        if (direct) hipLaunchKernelGGL(k_stereo_stats_t<true>, dim3(n_frames), dim3(WG), 0, st, p);
+        else hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(n_frames), dim3(WG), 0, st, p);
     }
     if (!direct)
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits,
@@ -1042,7 +1044,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         bool have_orbits = false;
         if (!planar_direct) have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, r.f0, r.fcount, st);
         if (!have_orbits) launch_orbits(r, c->d_orbits, st);
-        if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats, dim3(r.fcount), dim3(WG), 0, st, r);
+        if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(r.fcount), dim3(WG), 0, st, r);
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits, (const unsigned long long *)nullptr);
         if (lpc) {
             dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);

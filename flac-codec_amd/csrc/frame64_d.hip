@@ -14,7 +14,8 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st) {
+void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
+    (void)B;   // 4096-sample blocks only (flacenc_gpu.hip: direct_input_ok)
     if (p.max_lpc_order > 16) launch_frame64_nt<128, 64, 32, true>(p, q, frames, lds, st);
     else launch_frame64_nt<128, 64, 16, true>(p, q, frames, lds, st);
 }

@@ -133,7 +133,7 @@ void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 // persistent stereo kernels: K6 in the workgroup) -- no k_decide launch for those frames then
 bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_direct.hip
-void launch_cand64_direct(const Params &p, uint32_t blocks, hipStream_t st);
+bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
 // autocorr.hip
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st);
@@ -150,7 +150,7 @@ void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t f
 hipError_t pack_set_attributes(size_t pack_lds);
 // frame64_a.hip / frame64_b.hip / frame64_c.hip
 void launch_frame64_4096(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
-void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
+void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_deep(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_short(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds,
                           hipStream_t st);

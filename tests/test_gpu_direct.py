@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 B = 4096
 
 
-def encode(pcm, bps, max_lpc, monkeypatch, direct, mid_side=True, rate=48000, first=5):
+def encode(pcm, bps, max_lpc, monkeypatch, direct, mid_side=True, rate=48000, first=5, B=B, exhaustive=True, max_po=6):
     from flac_codec_amd.gpu import GpuAnalyzer
 
     if direct:
@@ -22,7 +22,7 @@ def encode(pcm, bps, max_lpc, monkeypatch, direct, mid_side=True, rate=48000, fi
     else:
         monkeypatch.setenv("FLACGPU_NO_DIRECT", "1")
     n = pcm.size // (2 * B)
-    an = GpuAnalyzer(B, 6, max_lpc, mid_side, True, 2, 0.5, bps, 2, max_frames=n)
+    an = GpuAnalyzer(B, max_po, max_lpc, mid_side, exhaustive, 2, 0.5, bps, 2, max_frames=n)
     data, off = an.encode_frames(pcm, n, B, first, rate)
     kernels_ms = None
     an.set_timing(True)
@@ -39,17 +39,17 @@ def encode(pcm, bps, max_lpc, monkeypatch, direct, mid_side=True, rate=48000, fi
     return data, off, kernels_ms, (plans, subs, resid), st
 
 
-def check(pcm, bps, monkeypatch, max_lpc=12, mid_side=True, rate=48000):
+def check(pcm, bps, monkeypatch, max_lpc=12, mid_side=True, rate=48000, B=B, exhaustive=True, max_po=6):
     from flac_codec_amd.gpu import host_pack_frames
 
     first = 5
     pcm = np.ascontiguousarray(pcm, dtype=np.int32)
     n = pcm.size // (2 * B)
-    d_data, d_off, d_ms, d_plans, _ = encode(pcm, bps, max_lpc, monkeypatch, True, mid_side, rate, first)
-    k_data, k_off, k_ms, _, _ = encode(pcm, bps, max_lpc, monkeypatch, False, mid_side, rate, first)
+    d_data, d_off, d_ms, d_plans, _ = encode(pcm, bps, max_lpc, monkeypatch, True, mid_side, rate, first, B, exhaustive, max_po)
+    k_data, k_off, k_ms, _, _ = encode(pcm, bps, max_lpc, monkeypatch, False, mid_side, rate, first, B, exhaustive, max_po)
     assert "k_deinterleave" not in d_ms and "k_deinterleave" in k_ms   # the split pass really was skipped
     assert d_off == k_off and d_data == k_data
-    oopts = orc_options_for(B, 6, max_lpc, mid_side, True)
+    oopts = orc_options_for(B, max_po, max_lpc, mid_side, exhaustive)
     for f, planar in enumerate(planar_frames(pcm, 2, B)):
         rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)
         assert rc == 0 and d_data[d_off[f]:d_off[f + 1]] == fb, f
@@ -105,6 +105,20 @@ def test_without_lpc(monkeypatch):
     x[2 * B:3 * B, 1] = 0
     check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0)
     check(synth_fast(952, 2, 24, B * 3), 24, monkeypatch, max_lpc=0, mid_side=False)
+
+
+def test_fast_channel_choice(monkeypatch):
+    """The fast channel choice with direct input: the abs sums come from the interleaved pairs
+    (k_stereo_stats_t<INTER>), the candidates' activity from the assignment; with and without LPC."""
+    check(synth_fast(965, 2, 24, 4096 * 5), 24, monkeypatch, max_lpc=12, exhaustive=False)
+    check(synth_fast(966, 2, 16, 4096 * 4), 16, monkeypatch, max_lpc=0, exhaustive=False, mid_side=False)
+    check(synth_fast(968, 2, 16, 4096 * 4), 16, monkeypatch, max_lpc=8, exhaustive=False, mid_side=False, max_po=5)
+    x = synth_fast(967, 2, 16, 4096 * 6).reshape(-1, 2).astype(np.int64)
+    x[:, 0] <<= 3
+    x[4096:8192] = 0
+    x[8192:12288, 1] = x[8192:12288, 0]
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False)
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=12, exhaustive=False)
 
 
 def test_device_buffer_input(monkeypatch):
