@@ -14,8 +14,10 @@ namespace flacgpu_k {
 bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
     const bool lpc = p.max_lpc_order > 0;
     if (B == FN) {
-        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
-        const uint32_t grid = blocks < cap ? blocks : cap;   // default: two workgroups per CU
+        static const bool split = getenv("FLACGPU_CAND_SPLIT") != nullptr;
+        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : (split ? 512u : 768u);
+        if (split && lpc) return launch_cand64_split(p, B, blocks, cap, st);
+        const uint32_t grid = blocks < cap ? blocks : cap;   // default: three workgroups per CU (165 VGPRs)
         if (!lpc)   // no k_autocorr4 / k_lpc before this kernel: it derives the candidate info itself
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
         else if (p.max_lpc_order > 16)

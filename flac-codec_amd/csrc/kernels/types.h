@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <type_traits>
 
 #include "flacenc_gpu.h"
 
@@ -134,6 +135,8 @@ void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_direct.hip
 bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
+// cand_split.hip: eight waves per stereo frame ({L, R, mid, side} x {FIXED, LPC}); false: shape not served
+bool launch_cand64_split(const Params &p, uint32_t B, uint32_t frames, uint32_t grid_cap, hipStream_t st);
 // autocorr.hip
 void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st);
