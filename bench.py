@@ -305,7 +305,8 @@ def main():
     args = ap.parse_args()
 
     if args.experiment == "mfma_autocorr":
-        os.environ["FLACGPU_EXPERIMENT_MFMA_AC"] = "1"   # read by the library when it first dispatches
+        os.environ["FLACGPU_TEST_KNOBS"] = "1"            # test-only knobs are ignored without this
+        os.environ["FLACGPU_EXPERIMENT_MFMA_AC"] = "1"   # read by the library when a context is created
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))

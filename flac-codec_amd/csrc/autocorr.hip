@@ -12,7 +12,7 @@ namespace {
 #include "kernels/autocorr.inc"
 
 template <int NL, bool STEREO>
-void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                       const double *win, hipStream_t st) {
     const uint32_t groups = (nframes * p.ncand + 63) / 64;
     // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
@@ -20,7 +20,7 @@ void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32
     // 0.31 ms split 2 ways).  When other contexts keep the SIMDs busy anyway, the 2-way split wins:
     // the int -> f64 x window conversion is replicated 2x instead of 4x (71 M instead of 92 M
     // instructions).
-    static const bool private_tiles = getenv("FLACGPU_AC_PRIVATE") != nullptr;  // previous kernel (A/B runs)
+    const bool private_tiles = kn.ac_private;  // previous kernel (A/B runs)
     if constexpr (STEREO) {
         if (p.inter) {   // interleaved input read in place (the host selects this only with the 4-way split)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
@@ -45,26 +45,26 @@ void launch_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32
                            frame0, nframes, n, win);
 }
 template <bool STEREO>
-void launch_autocorr3_nl(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+void launch_autocorr3_nl(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
                          hipStream_t st) {
     const uint32_t nl = p.max_lpc_order + 1;
-    if (nl <= 5) launch_autocorr3<5, STEREO>(p, frame0, nframes, n, win, st);
-    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, frame0, nframes, n, win, st);
-    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, frame0, nframes, n, win, st);
-    else launch_autocorr3<17, STEREO>(p, frame0, nframes, n, win, st);
+    if (nl <= 5) launch_autocorr3<5, STEREO>(p, kn, frame0, nframes, n, win, st);
+    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, kn, frame0, nframes, n, win, st);
+    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, kn, frame0, nframes, n, win, st);
+    else launch_autocorr3<17, STEREO>(p, kn, frame0, nframes, n, win, st);
 }
 // frame length a multiple of 32, order <= 16, and either stereo L/R/M/S candidates of <= 24-bit
 // samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
-bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+bool try_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
                    hipStream_t st) {
-    if (n < 32 || n % 32 != 0 || getenv("FLACGPU_NO_AC3")) return false;
+    if (n < 32 || n % 32 != 0 || kn.no_ac3) return false;
     const bool stereo = p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24;
     const bool indep = !p.stereo4 && p.ncand == p.channels;
     if (!stereo && !indep) return false;
     if (p.max_lpc_order > 16) {  // lags up to 32: two blocks of history, frame a multiple of 64
         if (n % 64 != 0) return false;
         const uint32_t groups = (nframes * p.ncand + 63) / 64;
-        static const bool private_deep = getenv("FLACGPU_AC_PRIVATE") != nullptr;
+        const bool private_deep = kn.ac_private;
         if (stereo && p.inter) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true, true>), dim3(groups), dim3(256), 0, st, p, frame0,
                                nframes, n, win);
@@ -84,8 +84,8 @@ bool try_autocorr3(const Params &p, uint32_t frame0, uint32_t nframes, uint32_t 
         }
         return true;
     }
-    if (stereo) launch_autocorr3_nl<true>(p, frame0, nframes, n, win, st);
-    else launch_autocorr3_nl<false>(p, frame0, nframes, n, win, st);
+    if (stereo) launch_autocorr3_nl<true>(p, kn, frame0, nframes, n, win, st);
+    else launch_autocorr3_nl<false>(p, kn, frame0, nframes, n, win, st);
     return true;
 }
 
@@ -99,18 +99,18 @@ void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_
 }  // namespace
 
 namespace flacgpu_k {
-void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st) {
     // EXPERIMENT switch (bench.py --experiment mfma_autocorr): the re-associating f64-MFMA kernel in
     // place of the exact one, to measure what a whole step costs with the autocorrelation off the
     // VALU pipe.  NOT bit-exact; never set in production.
-    static const bool mfma = getenv("FLACGPU_EXPERIMENT_MFMA_AC") != nullptr;
+    const bool mfma = kn.experiment_mfma_ac;
     if (mfma && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 && frame0 == 0 && nframes == p.n_frames &&
         n == p.block_size) {
         hipLaunchKernelGGL(k_autocorr_mfma, dim3((nframes * p.ncand + 3) / 4), dim3(WG), 0, st, p, n, win, p.ac);
         return;
     }
-    if (try_autocorr3(p, frame0, nframes, n, win, st)) return;
+    if (try_autocorr3(p, kn, frame0, nframes, n, win, st)) return;
     switch (H) {
     case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
     case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;

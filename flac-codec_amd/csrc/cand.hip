@@ -11,14 +11,14 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st) {
     // persistent variant with LDS prefetch: 4096-sample blocks, order <= 16, enough groups to go round
-    static const bool no_persist = getenv("FLACGPU_NO_PERSIST") != nullptr;
+    const bool no_persist = kn.no_persist;
     if (p.inter) {   // interleaved stereo input read in place: persistent kernels only (cand_direct.hip)
-        return launch_cand64_direct(p, B, blocks, st);
+        return launch_cand64_direct(p, kn, B, blocks, st);
     }
     if (!no_persist && B == FN && p.max_lpc_order > 16) {
-        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
+        const uint32_t cap = kn.cand_grid ? kn.cand_grid : 512u;
         const uint32_t grid = blocks < cap ? blocks : cap;
         const bool stereo = p.stereo4 && p.ncand == 4;
         if (stereo) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, true>), dim3(grid), dim3(WG), 0, st, p);
@@ -26,9 +26,11 @@ bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st)
         return stereo;
     }
     if (!no_persist && B == FN && p.max_lpc_order <= 16) {
-        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : 512u;
-        const uint32_t grid = blocks < cap ? blocks : cap;   // default: two workgroups per CU
         const bool stereo = p.stereo4 && p.ncand == 4;
+        // default: three workgroups per CU for the stereo kernel (165 VGPRs, 32 KB of LDS), two for independent
+        // channels (four 16 KB rows per workgroup)
+        const uint32_t cap = kn.cand_grid ? kn.cand_grid : (stereo ? 768u : 512u);
+        const uint32_t grid = blocks < cap ? blocks : cap;
         if (stereo) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true>), dim3(grid), dim3(WG), 0, st, p);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, false>), dim3(grid), dim3(WG), 0, st, p);
         return stereo;

@@ -11,11 +11,11 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st) {
+bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st) {
     const bool lpc = p.max_lpc_order > 0;
     if (B == FN) {
-        static const bool split = getenv("FLACGPU_CAND_SPLIT") != nullptr;
-        static const uint32_t cap = getenv("FLACGPU_CAND_GRID") ? (uint32_t)atoi(getenv("FLACGPU_CAND_GRID")) : (split ? 512u : 768u);
+        const bool split = kn.cand_split;   // experiment: eight waves per frame (profiles/r03_cand_split.json)
+        const uint32_t cap = kn.cand_grid ? kn.cand_grid : (split ? 512u : 768u);
         if (split && lpc) return launch_cand64_split(p, B, blocks, cap, st);
         const uint32_t grid = blocks < cap ? blocks : cap;   // default: three workgroups per CU (165 VGPRs)
         if (!lpc)   // no k_autocorr4 / k_lpc before this kernel: it derives the candidate info itself

@@ -49,6 +49,33 @@
 
 thread_local std::string g_last_error;
 
+// Every FLACGPU_* environment knob (kernels/types.h Knobs), read when a context is created.  The test-only knobs
+// are ignored unless FLACGPU_TEST_KNOBS=1 accompanies them: a production process cannot be skewed by a stray variable.
+Knobs read_knobs() {
+    Knobs k;
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    k.no_direct = on("FLACGPU_NO_DIRECT");
+    k.no_fast = on("FLACGPU_NO_FAST");
+    k.no_w64 = on("FLACGPU_NO_W64");
+    k.no_persist = on("FLACGPU_NO_PERSIST");
+    k.no_ac3 = on("FLACGPU_NO_AC3");
+    k.ac_private = on("FLACGPU_AC_PRIVATE");
+    k.no_fused_pack = on("FLACGPU_NO_FUSED_PACK");
+    k.no_frame64 = on("FLACGPU_NO_FRAME64");
+    k.no_fork = on("FLACGPU_NO_FORK");
+    k.lpc_dyn = on("FLACGPU_LPC_DYN");
+    k.cand_split = on("FLACGPU_CAND_SPLIT");
+    if (const char *e = getenv("FLACGPU_CAND_GRID")) k.cand_grid = (uint32_t)atoi(e);
+    const char *t = getenv("FLACGPU_TEST_KNOBS");
+    if (t && t[0] == '1') {
+        k.experiment_mfma_ac = on("FLACGPU_EXPERIMENT_MFMA_AC");
+        if (const char *e = getenv("FLACGPU_TIE_BAND")) { k.has_tie_band = true; k.tie_band = atof(e); }
+        if (const char *e = getenv("FLACGPU_TIE_PERTURB")) { k.has_tie_perturb = true; k.tie_perturb = atof(e); }
+        if (const char *e = getenv("FLACGPU_DECODE_LANES")) k.decode_lanes = (uint32_t)atoi(e);
+    }
+    return k;
+}
+
 namespace {
 #include "kernels/common.inc"
 #include "kernels/k0_split.inc"
@@ -78,6 +105,7 @@ struct flacgpu_ctx {
     uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate); = d_stats + 4
     uint32_t *d_ties = nullptr;     // candidates whose LPC order estimates tie (k_lpc), [F * NC]
     double tie_band = 1e-9, tie_perturb = 0.0;
+    Knobs knobs;                  // the FLACGPU_* environment, read once at flacgpu_create
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
     uint32_t ties_resolved = 0;     // candidates re-decided on the host for the last analysis
     uint32_t last_n_fast = 0;       // frames of the last analysis that took the wave kernels
@@ -418,8 +446,9 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
     ALLOC(c->d_ties, F * NC);
     if (c->stereo4 && !o->exhaustive_channel_correlation) ALLOC(c->d_abs, F * 4);
-    if (const char *e = getenv("FLACGPU_TIE_BAND")) c->tie_band = atof(e);         // test knobs
-    if (const char *e = getenv("FLACGPU_TIE_PERTURB")) c->tie_perturb = atof(e);
+    c->knobs = read_knobs();
+    if (c->knobs.has_tie_band) c->tie_band = c->knobs.tie_band;            // test knobs
+    if (c->knobs.has_tie_perturb) c->tie_perturb = c->knobs.tie_perturb;
 #undef ALLOC
     // non-blocking: contexts must not synchronise with each other through the legacy null stream
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -542,10 +571,9 @@ static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
 // 1152-sample blocks, more than the split pass costs), and every stage on its wave kernel -- none of the knobs
 // that select an older or generic kernel (they read Params::planar).
 static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
-    const bool off = getenv("FLACGPU_NO_DIRECT") || getenv("FLACGPU_NO_FAST") || getenv("FLACGPU_NO_W64") ||
-                            getenv("FLACGPU_NO_PERSIST") || getenv("FLACGPU_NO_AC3") || getenv("FLACGPU_AC_PRIVATE") ||
-                            getenv("FLACGPU_EXPERIMENT_MFMA_AC") || getenv("FLACGPU_NO_FUSED_PACK") ||
-                            getenv("FLACGPU_NO_FRAME64");
+    const Knobs &kn = c->knobs;
+    const bool off = kn.no_direct || kn.no_fast || kn.no_w64 || kn.no_persist || kn.no_ac3 || kn.ac_private ||
+                     kn.experiment_mfma_ac || kn.no_fused_pack || kn.no_frame64;
     const uint32_t B = p.block_size;
     return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B &&
            p.max_po <= 6 && p.ac_split != 2 &&
@@ -638,7 +666,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // K0 (+ OR of every candidate's samples -> wasted bits)
     // (one channel: interleaved and planar are the same bytes -- no copy either)
     const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
-                               last_len == B && !getenv("FLACGPU_NO_DIRECT");
+                               last_len == B && !c->knobs.no_direct;
     if (!direct) begin(0);
     bool have_orbits = direct;
     if (direct) {
@@ -663,11 +691,11 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
                            c->abs_valid ? c->d_abs : nullptr);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other
     // block sizes, a short last frame, candidates wider than 25 bits) the generic LDS ones
-    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
+    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !c->knobs.no_fast;
     // wave-per-candidate kernel (FIXED + LPC analysis of a candidate in one wave, after the LPC
     // parameters are known): block lengths 64 x {16, 18, 32, 36, 64}, LPC order <= 16
     const bool w64 = narrow && wave_block_size(B) && (p.max_lpc_order <= 16 || B == FN) && p.max_po <= 6 &&
-                     !getenv("FLACGPU_NO_W64");
+                     !c->knobs.no_w64;
     const uint32_t n_fast = w64 ? ((last_len == B) ? n_frames : n_frames - 1) : 0;
     Params pf = p, pg = p;
     pf.f0 = 0;
@@ -678,7 +706,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // Otherwise the FIXED analysis and the autocorrelation -> Levinson chain, which only share
     // their input, run concurrently on two HIP streams (fork after k_candinfo, join before
     // k_fir).  With per-kernel timing enabled everything is serialised on one stream.
-    const bool fork = lpc && !c->timing && !getenv("FLACGPU_NO_FORK") && !(w64 && pg.fcount == 0);
+    const bool fork = lpc && !c->timing && !c->knobs.no_fork && !(w64 && pg.fcount == 0);
     hipStream_t sf = fork ? c->aux_stream : st;
     if (fork) {
         HIP_TRY(hipEventRecord(c->ev_fork, st));
@@ -694,10 +722,10 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
         begin(3);
         const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
-        if (full) dispatch_autocorr(H, p, 0, full, B, c->d_window_full, st);
-        if (full != n_frames) dispatch_autocorr(H, p, full, 1, last_len, c->d_window_last, st);
+        if (full) dispatch_autocorr(H, p, c->knobs, 0, full, B, c->d_window_full, st);
+        if (full != n_frames) dispatch_autocorr(H, p, c->knobs, full, 1, last_len, c->d_window_last, st);
         begin(4);
-        launch_lpc(p, (ncb + 63) / 64, st);
+        launch_lpc(p, c->knobs, (ncb + 63) / 64, st);
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         if (pg.fcount) {
             begin(5);
@@ -708,7 +736,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     bool decided = false;   // the persistent stereo kernels choose the channel assignment themselves
     if (w64 && pf.fcount) {
         begin(11);
-        decided = launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
+        decided = launch_cand64(pf, c->knobs, B, (pf.fcount * c->ncand + 3) / 4, st);
     }
     if (!decided) {
         begin(6);
@@ -805,7 +833,7 @@ static int resolve_order_ties(flacgpu_ctx *c) {
         else hipLaunchKernelGGL(k_fir_t<false>, dim3(pg.fcount * c->ncand), dim3(WG), dyn2, st, pg);
     }
     bool decided = false;
-    if (pf.fcount) decided = launch_cand64(pf, B, (pf.fcount * c->ncand + 3) / 4, st);
+    if (pf.fcount) decided = launch_cand64(pf, c->knobs, B, (pf.fcount * c->ncand + 3) / 4, st);
     if (!decided) hipLaunchKernelGGL(k_decide, dim3(p.n_frames), dim3(64), 0, st, p);
     else if (pg.fcount) hipLaunchKernelGGL(k_decide, dim3(pg.fcount), dim3(64), 0, st, pg);
     HIP_TRY(hipGetLastError());
@@ -908,7 +936,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     // through k_emit (residual rows) -> k_pack (one workgroup per subframe, zero-filled output,
     // atomic OR at shared words) -> k_crc
     const uint32_t B = p.block_size;
-    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !getenv("FLACGPU_NO_FAST");
+    const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !c->knobs.no_fast;
     const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
     // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}; orders 17..32 and 5..8 channels
     // for 4096-sample blocks only (and not both)
@@ -916,7 +944,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
                       (p.max_lpc_order <= 16 || (B == FN && p.channels <= 4)) &&
                       (p.channels <= 4 || B == FN) && p.max_po <= 6 &&
                       (size_t)fbw * sizeof(int32_t) <= 150 * 1024 &&
-                      !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64");
+                      !c->knobs.no_fused_pack && !c->knobs.no_frame64;
     const uint32_t n_fast = f64w ? (p.last_len == B ? p.n_frames : p.n_frames - 1) : 0;
     const bool fused = n_fast != 0;
     Params pf = p, pg = p;
@@ -1004,8 +1032,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) &&
         (c->opts.max_lpc_order <= 16 || (B == FN && c->channels <= 4)) &&
         c->opts.max_partition_order <= 6 && (c->channels <= 4 || B == FN) && (layout == 0 || layout == 1) &&
-        (size_t)fbw * sizeof(int32_t) <= 150 * 1024 && !c->timing && !getenv("FLACGPU_NO_FAST") &&
-        !getenv("FLACGPU_NO_W64") && !getenv("FLACGPU_NO_FUSED_PACK") && !getenv("FLACGPU_NO_FRAME64") &&
+        (size_t)fbw * sizeof(int32_t) <= 150 * 1024 && !c->timing && !c->knobs.no_fast &&
+        !c->knobs.no_w64 && !c->knobs.no_fused_pack && !c->knobs.no_frame64 &&
         c->two_ranges;
     hipStream_t st0;
     if (int rc = resolve_stream(c, stream, &st0)) return rc;
@@ -1047,10 +1075,10 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(r.fcount), dim3(WG), 0, st, r);
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits, (const unsigned long long *)nullptr);
         if (lpc) {
-            dispatch_autocorr(H, r, r.f0, r.fcount, B, c->d_window_full, st);
-            launch_lpc(r, (ncb + 63) / 64, st);
+            dispatch_autocorr(H, r, c->knobs, r.f0, r.fcount, B, c->d_window_full, st);
+            launch_lpc(r, c->knobs, (ncb + 63) / 64, st);
         }
-        if (!launch_cand64(r, B, (ncb + 3) / 4, st)) hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
+        if (!launch_cand64(r, c->knobs, B, (ncb + 3) / 4, st)) hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's
         if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
         launch_layout(r, q, st);
@@ -1645,8 +1673,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     {
         const uint32_t units = p.n_frames * p.channels;
         uint32_t lanes = 32;
-        if (const char *e = getenv("FLACGPU_DECODE_LANES")) {  // experiment knob
-            const uint32_t v = (uint32_t)atoi(e);
+        if (const uint32_t v = c->knobs.decode_lanes) {  // experiment knob
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) lanes = v;
         }
         launch_decode(c->opts.max_lpc_order, units, lanes, pd, q, c->d_decoded, c->d_verify, st);

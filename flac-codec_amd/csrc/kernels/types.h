@@ -124,21 +124,36 @@ __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_
 // block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
 #define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
 
+// Every FLACGPU_* environment knob, resolved ONCE per context (flacgpu_create; flacenc_gpu.hip read_knobs) -- the
+// dispatch path never calls getenv.  The A/B selectors keep an older or generic kernel reachable for measurements
+// and parity tests; the TEST knobs (tie_band, tie_perturb, experiment_mfma_ac, decode_lanes) are honoured only
+// when FLACGPU_TEST_KNOBS=1 is set as well.
+struct Knobs {
+    bool no_direct = false, no_fast = false, no_w64 = false, no_persist = false, no_ac3 = false, ac_private = false,
+         no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false;
+    uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
+    bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
+    bool has_tie_band = false, has_tie_perturb = false;
+    double tie_band = 0.0, tie_perturb = 0.0;   // TEST
+    uint32_t decode_lanes = 0;          // TEST: lanes per wave of the stand-alone decoder, 0: default
+};
+Knobs read_knobs();   // flacenc_gpu.hip
+
 // ---- launchers (one per kernel family; defined in the .hip file that holds the kernels) ----
 namespace flacgpu_k {
 // lpc.hip
-void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st);
+void launch_lpc(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t st);
 void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 // cand.hip
 // returns true when the kernel also chose the channel assignment and wrote out_plan / frame_plan (the
 // persistent stereo kernels: K6 in the workgroup) -- no k_decide launch for those frames then
-bool launch_cand64(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);
+bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_direct.hip
-bool launch_cand64_direct(const Params &p, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
+bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
 // cand_split.hip: eight waves per stereo frame ({L, R, mid, side} x {FIXED, LPC}); false: shape not served
 bool launch_cand64_split(const Params &p, uint32_t B, uint32_t frames, uint32_t grid_cap, hipStream_t st);
 // autocorr.hip
-void dispatch_autocorr(uint32_t H, const Params &p, uint32_t frame0, uint32_t nframes, uint32_t n,
+void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st);
 void launch_autocorr_mfma(const Params &p, uint32_t blocks, uint32_t n, const double *win, double *ac,
                           hipStream_t st);

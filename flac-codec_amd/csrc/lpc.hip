@@ -11,11 +11,11 @@ namespace {
 }  // namespace
 
 namespace flacgpu_k {
-void launch_lpc(const Params &p, uint32_t blocks, hipStream_t st) {
+void launch_lpc(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t st) {
     if (p.max_lpc_order <= 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<8>), dim3(blocks), dim3(64), 0, st, p);
     else if (p.max_lpc_order <= 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<12>), dim3(blocks), dim3(64), 0, st, p);
     else if (p.max_lpc_order <= 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<16>), dim3(blocks), dim3(64), 0, st, p);
-    else if (getenv("FLACGPU_LPC_DYN")) hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
+    else if (kn.lpc_dyn) hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<32>), dim3(blocks), dim3(64), 0, st, p);
 }
 void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st) {

@@ -78,6 +78,26 @@ def test_fast_preset():  # Options::fast(): block 1152, no LPC, no mid-side, abs
              mid_side=True, exhaustive=False)
 
 
+def test_fast_channel_choice_wide_samples():
+    """31-bit stereo, channel choice by abs sums (encode.rs:2463-2674 sums in u64): near-full-scale
+    anti-correlated channels make |side| reach 2^31 per sample, so partial sums held in 32 bits would
+    wrap and could pick another assignment than the reference."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 4096 * 3 + 500
+    l = rng.integers((1 << 30) - (1 << 27), (1 << 30) - 1, size=n, dtype=np.int64)
+    l *= np.where(np.arange(n) % 7 < 4, 1, -1)                     # long runs at either rail
+    r = -l + rng.integers(-(1 << 12), 1 << 12, size=n, dtype=np.int64)
+    r = np.clip(r, -(1 << 30), (1 << 30) - 1)
+    pcm = np.stack([l, r], axis=1).astype(np.int32).reshape(-1)
+    for ms in (True, False):
+        run_case(pcm, 2, 31, max_lpc=8, mid_side=ms, exhaustive=False)
+        run_case(pcm, 2, 31, max_lpc=0, mid_side=ms, exhaustive=False, block_size=1152, max_po=3)
+    # the same shape at 29 and 30 bits (the extreme case of the former 8-sample u32 partial sums)
+    for bps in (29, 30):
+        sh = 31 - bps
+        run_case((pcm >> sh).astype(np.int32), 2, bps, max_lpc=8, exhaustive=False)
+
+
 def test_no_mid_side_exhaustive():
     run_case(synth_fast(72, 2, 24, 4096 * 4), 2, 24, mid_side=False)
 
@@ -184,6 +204,7 @@ def test_order_ties_are_redecided_on_the_host(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        monkeypatch.setenv("FLACGPU_TEST_KNOBS", "1")   # the tie knobs are test-only: ignored without this
         an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 16, 2, max_frames=len(frames))
         data, off = an.encode_frames(pcm, len(frames), 4096, 0, 48000)
         st = an.stats()
