@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflacenc_amd.so")
+# FLACENC_AMD_LIBRARY: another build of the same library (the sanitizer builds of csrc/Makefile `sanitize`)
+LIB_PATH = os.environ.get("FLACENC_AMD_LIBRARY") or os.path.join(_HERE, "libflacenc_amd.so")
 
 MAX_CHANNELS = 8
 MAX_LPC_ORDER = 32
