@@ -72,13 +72,33 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n):
-    """--gpus N without torchrun: N children of this script, one per GPU.  Nothing in this
-    (parent) process touches a GPU: device_count() does not initialise one."""
-    import torch
+def count_gpus_without_hip():
+    """GPUs this process may use, WITHOUT loading the HIP runtime (on this pool a process that has touched the
+    GPU must not be the one whose children exec; torch.cuda.device_count() can fall back to hipGetDeviceCount):
+    the KFD topology (nodes with SIMDs are GPUs) narrowed by the visibility variables."""
+    import glob
 
-    have = torch.cuda.device_count()
-    if have < n:
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(props):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n, popen=subprocess.Popen):
+    """--gpus N without torchrun: N children of this script, one per GPU.  Nothing in this (parent) process
+    loads torch or the HIP runtime (tests/test_bench_launch.py checks /proc/self/maps at spawn time)."""
+    have = count_gpus_without_hip()
+    if have < n and os.environ.get("FLAC_BENCH_SHARE_DEVICE") != "1":
         sys.stderr.write(f"bench.py: --gpus {n} asked for, but this box has {have} GPU(s); "
                          f"refusing to report a line for fewer ranks than requested\n")
         sys.exit(2)
@@ -87,7 +107,7 @@ def launch_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
         rc = max(rc, abs(p.wait()))
@@ -277,6 +297,257 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     return out
 
 
+
+
+KERNEL_PROFILE_NAMES = {"k_autocorr": "k_autocorr4", "k_deinterleave": "k_deinterleave2", "k_pack": "k_frame64",
+                        "k_cand64": "k_cand64p"}
+
+
+class Workload:
+    """One BASELINE configuration resident on this rank's GPU: `contexts` encoder contexts on their own HIP
+    streams, each reading ITS OWN device buffer of synthetic PCM (a streaming encoder never re-reads its input:
+    distinct buffers keep one context's batch out of the Infinity Cache of the next)."""
+
+    def __init__(self, torch, cfg_id, frames, first_frame, contexts, device, seed_rank, lag_split=0, pcm=None):
+        from flac_codec_amd.gpu import GpuAnalyzer
+
+        self.torch = torch
+        self.cfg_id, self.cfg = cfg_id, CONFIGS[cfg_id]
+        c = self.cfg
+        self.C, self.BPS, self.RATE, self.LPC, self.PO = c["ch"], c["bps"], c["rate"], c["lpc"], c["po"]
+        self.F, self.first_frame = frames, first_frame
+        # context i encodes its own PCM (seed differs); `pcm` given: every context the caller's samples (strong
+        # scaling: the rank's range of ONE stream)
+        self.pcm = [pcm if pcm is not None else make_pcm(1000 + 16 * cfg_id + seed_rank + 101 * i, frames, self.C, self.BPS)
+                    for i in range(contexts)]
+        self.d_pcm = [torch.from_numpy(p).cuda() for p in self.pcm]
+        self.ans = [GpuAnalyzer(BLOCK, self.PO, self.LPC, True, True, 2, 0.5, self.BPS, self.C, max_frames=frames,
+                                device=device) for _ in range(contexts)]
+        if lag_split:
+            for a in self.ans:
+                a.set_tuning(a.TUNE_LAG_SPLIT, lag_split)
+        self.streams = [torch.cuda.Stream() for _ in self.ans]
+        self.n = 0
+        self.same_buffer = False     # A/B: every context reads buffer 0 (what the r02 bench did)
+        self.only_first = False      # one context, kernels back to back
+
+    def step(self):   # analysis + frame assembly of one whole batch (flacgpu_encode_device)
+        i = 0 if self.only_first else self.n % len(self.ans)
+        self.n += 1
+        src = self.d_pcm[0 if self.same_buffer else i]
+        self.ans[i].encode_device(src.data_ptr(), self.F, BLOCK, self.first_frame, self.RATE,
+                                  stream=self.streams[i].cuda_stream)
+
+    def prewarm(self, ms):
+        torch = self.torch
+        t = time.perf_counter()
+        steps = 0
+        while (time.perf_counter() - t) * 1e3 < ms:
+            for _ in range(8):
+                self.step()
+            torch.cuda.synchronize()
+            steps += 8
+        return steps
+
+    def timed(self, k, dist=None):
+        torch = self.torch
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            self.step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def parity(self, orc, experiment=False):
+        """EVERY context's last batch: all distinct frames byte-compared with the oracle, the whole batch decoded
+        back and compared with its input on the device.  Returns (ok, identical, differ, compressed_bytes, verify)."""
+        from _compare import orc_options_for
+
+        oopts = orc_options_for(BLOCK, self.PO, self.LPC, True, True)
+        check = min(DISTINCT, self.F)
+        ok, identical, differ = True, 0, 0
+        compressed = None
+        verify = None
+        C = self.C
+        for i, an in enumerate(self.ans):
+            # one more batch from the context's own buffer through the timed entry point (the A/B loops after the
+            # timed region may have left another buffer's frames in it)
+            an.encode_device(self.d_pcm[i].data_ptr(), self.F, BLOCK, self.first_frame, self.RATE,
+                             stream=self.streams[i].cuda_stream)
+            self.torch.cuda.synchronize()
+            data, off = an.fetch_frames(self.F)
+            if compressed is None:
+                compressed = off[self.F]
+            pcm = self.pcm[i]
+            for f in range(check):
+                planar = np.ascontiguousarray(pcm[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
+                rc, fb, _ = orc.encode_frame(oopts, self.RATE, self.BPS, planar, frame_number=self.first_frame + f)
+                if rc != 0 or data[off[f]:off[f + 1]] != fb:
+                    differ += 1
+                    if not experiment:
+                        sys.stderr.write(f"config {self.cfg_id} context {i}: frame {f} differs from the oracle\n")
+                        ok = False
+                        break
+                else:
+                    identical += 1
+            an.analyze_device(self.d_pcm[i].data_ptr(), self.F, BLOCK)
+            an.pack_device(self.first_frame, self.RATE)
+            vres, vms = an.verify_device(self.RATE, self.first_frame)
+            if (vres.bad_structure, vres.bad_crc16, vres.frames_pcm_differs) != (0, 0, 0):
+                ok = False
+            if verify is None:
+                verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
+                          "Msamples/s": round(self.F * BLOCK * C / (vms * 1e-3) / 1e6, 1)}
+        return ok, identical, differ, compressed, verify
+
+    def kernel_times(self, reps=10):
+        """Per-kernel durations (HIP events on the launch stream inside the library), taken from steady-state
+        batches: the clocks are re-warmed right before, three untimed passes, then `reps` passes back to back."""
+        an, d = self.ans[0], self.d_pcm[0]
+        self.prewarm(150.0)
+        an.set_timing(True)
+        acc = {}
+        for r in range(3 + reps):
+            an.analyze_device(d.data_ptr(), self.F, BLOCK)
+            ms_a = an.kernel_ms()
+            an.pack_device(self.first_frame, self.RATE)
+            ms_b = an.kernel_ms()
+            if r >= 3:
+                for k, v in {**ms_a, **ms_b}.items():
+                    acc[k] = acc.get(k, 0.0) + v / reps
+        an.set_timing(False)
+        return {k: v for k, v in acc.items() if v > 0}
+
+    def algorithmic(self, compressed_bytes):
+        """algorithmic bytes / flops per launch (DESIGN.md "Kernels")"""
+        F, C = self.F, self.C
+        n_cand = (4 if C == 2 else C) * F          # L, R, M, S per stereo frame; one per channel otherwise
+        cand_samples = n_cand * BLOCK
+        return {
+            "k_deinterleave": ("hbm", 8.0 * F * BLOCK * C),
+            "k_autocorr": ("f64", 2.0 * BLOCK * (self.LPC + 1) * n_cand),
+            # fused FIXED + LPC + Rice search: every candidate's samples are read once, residuals
+            # never leave registers, 280-byte plan out
+            "k_cand64": ("hbm", 4.0 * cand_samples + 280.0 * n_cand),
+            # k_frame64 (reported in the k_pack slot): samples in, finished frame bytes out
+            "k_pack": ("hbm", 4.0 * F * BLOCK * C + compressed_bytes),
+        }
+
+    def kernels_report(self, compressed_bytes):
+        acc = self.kernel_times()
+        alg = self.algorithmic(compressed_bytes)
+        kernels = {}
+        for k, ms in acc.items():
+            entry = {"ms": round(ms, 4)}
+            if k in alg:
+                kind, amount = alg[k]
+                entry["GB/s" if kind == "hbm" else "GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+            kernels[k] = entry
+        hbm = {k: v for k, v in kernels.items() if "GB/s" in v}
+        dom = max(hbm, key=lambda k: hbm[k]["ms"])
+        return kernels, dom, alg
+
+    def close(self):
+        for a in self.ans:
+            a.close()
+        self.d_pcm = None
+
+
+def profile_figures(cfg_id, dom, dom_ms):
+    """HBM bytes and VALU instructions per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
+    this same command (tools/collect_profiles.sh; corrected as MI355X_MICROARCH.md prescribes) -- deterministic
+    for a given input and workload -- and the instruction-issue floor of tools/issue_floor.py."""
+    traffic = traffic_src = valu = None
+    tag = "" if cfg_id == 3 else f"cfg{cfg_id}_"
+    pdir = os.path.join(ROOT, "profiles")
+    key = KERNEL_PROFILE_NAMES.get(dom, dom)
+    try:
+        prof = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json") and (("cfg" in f) == bool(tag)) and tag in f)
+        t = json.load(open(os.path.join(pdir, prof[-1])))
+        k2 = key if key in t else (key[:-1] if key.endswith("p") and key[:-1] in t else None)
+        if k2:
+            traffic = t[k2]["hbm_bytes"]
+            traffic_src = {"source": "profiles/" + prof[-1], "kernel": k2,
+                           "fetch_bytes": t[k2].get("fetch_bytes"), "write_bytes": t[k2].get("write_bytes")}
+    except Exception:
+        pass
+    try:
+        vprof = sorted(f for f in os.listdir(pdir) if f.endswith("_valu.json") and (("cfg" in f) == bool(tag)) and tag in f)
+        vt = json.load(open(os.path.join(pdir, vprof[-1])))
+        k2 = key if key in vt else (key[:-1] if key.endswith("p") and key[:-1] in vt else None)
+        if k2 and vt[k2].get("SQ_INSTS_VALU"):
+            insts = vt[k2]["SQ_INSTS_VALU"]
+            valu = {"wave_insts_per_launch": insts, "source": "profiles/" + vprof[-1],
+                    "achieved_Ginst/s": round(insts / (dom_ms * 1e-3) / 1e9, 1),
+                    "nominal_peak_Ginst/s": round(VALU_ISSUE_PEAK / 1e9, 1),
+                    "frac_of_nominal_4_cycle_peak": round(insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, 4),
+                    "valu_active_per_wave_cycle": vt[k2].get("valu_active_per_wave_cycle"),
+                    "note": "the 4-cycle peak is a model; attainable_ms below is the floor from the kernel's own "
+                            "instruction mix at MEASURED per-class issue costs (profiles/r03_issue_rate_ubench.json)"}
+    except Exception:
+        pass
+    try:
+        fl = json.load(open(os.path.join(pdir, "r03_issue_floor.json")))
+        e = fl.get(f"config{cfg_id}", {}).get(dom)
+        if e and valu is not None:
+            valu["attainable_ms"] = e["attainable_ms"]
+            valu["attainable_source"] = "profiles/r03_issue_floor.json (tools/issue_floor.py)"
+            valu["frac_of_attainable"] = round(e["attainable_ms"] / dom_ms, 4)
+    except Exception:
+        pass
+    return traffic, traffic_src, valu
+
+
+def measure_other_config(torch, cfg_id, args, device, orc):
+    """A BASELINE configuration that is not the headline one, at its SURVEY 8(d) size: ms/step over `steps` timed steps
+    of the same multi-context loop, every context's distinct frames against the oracle, the dominant kernel and its
+    recomputed roofline fraction."""
+    t_wall = time.perf_counter()
+    w = Workload(torch, cfg_id, args.frames, 0, args.contexts, device, 0)
+    pre = w.prewarm(200.0)
+    for _ in range(3):
+        w.step()
+    steps = args.other_steps
+    el = w.timed(steps)
+    ms = el / steps * 1e3
+    ok, identical, differ, compressed, verify = w.parity(orc)
+    assert ok, f"config {cfg_id}: parity check failed"
+    kernels, dom, alg = w.kernels_report(compressed)
+    traffic, traffic_src, valu = profile_figures(cfg_id, dom, kernels[dom]["ms"])
+    cfg = w.cfg
+    out = {"workload": cfg["text"], "level": cfg["level"], "frames_per_step": w.F, "contexts": len(w.ans), "steps": steps,
+           "ms_per_step": round(ms, 4), "Msamples/s": round(w.F * BLOCK * w.C / (ms * 1e-3) / 1e6, 1),
+           "prewarm_steps": pre,
+           "frames_byte_identical_to_oracle": identical, "frames_checked": identical + differ,
+           "frames_round_tripped_on_device": w.F * len(w.ans),
+           "dominant_kernel": {"kernel": dom, "avg_launch_ms": kernels[dom]["ms"], "algorithmic_bytes": alg[dom][1],
+                               "achieved_GB/s": kernels[dom]["GB/s"], "frac": round(kernels[dom]["GB/s"] / HBM_PEAK_GBS, 4),
+                               "traffic": traffic, "traffic_source": traffic_src, "valu_issue": valu},
+           "kernels": kernels,
+           "compression_ratio": round(compressed / (w.F * BLOCK * w.C * ((w.BPS + 7) // 8)), 4)}
+    w.close()
+    out["wall_s"] = round(time.perf_counter() - t_wall, 1)
+    return out
+
+
+def metric_text(cfg, bit_exact):
+    what = {2: "level 5 (fixed predictors only), 48kHz/16-bit stereo", 3: "level 8, 48kHz/24-bit stereo",
+            4: "level 8, 192kHz/24-bit 8-channel", 5: "level 8 exhaustive (LPC order 32), 96kHz/24-bit stereo"}[cfg]
+    return f"Msamples/s encode at {what}" + ("; bit-exact vs reference" if bit_exact else "; NOT bit-exact (experiment)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,9 +555,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (SURVEY.md 8(d)); 3 is the headline metric")
-    ap.add_argument("--frames", type=int, default=FRAMES, help="FLAC frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=FRAMES,
+                    help="FLAC frames per step: per GPU (weak scaling) or of the whole stream (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank encodes --frames frames of its own; strong: ONE stream of --frames frames, "
+                         "contiguous frame ranges per rank (SURVEY.md 8(d) config 4)")
+    ap.add_argument("--emit-flac", default=None,
+                    help="strong scaling: rank 0 writes the whole .flac (frames gathered from the ranks, metadata rebuilt "
+                         "from the gathered sizes) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the other_configs block (BASELINE configs 2, 4, 5 next to the headline one)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of every other_configs entry")
     ap.add_argument("--e2e-batch-frames", type=int, default=0,
                     help="batch_frames of the writers in the end_to_end block (0: the library default)")
     ap.add_argument("--contexts", type=int, default=4, choices=(1, 2, 3, 4, 5, 6),
@@ -315,145 +596,123 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("FLAC_BENCH_SHARE_DEVICE") == "1"   # TEST: all ranks on GPU 0, gloo collectives
 
     import torch
 
+    if share:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)\n")
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist_mod.init_process_group(backend="gloo" if share else "nccl", rank=rank, world_size=world)
         dist = dist_mod
 
-    from flac_codec_amd.gpu import GpuAnalyzer
-    from flac_codec_amd.parallel import gather_shard_counters
+    from flac_codec_amd.parallel import gather_shard_counters, shard_range
 
     cfg = CONFIGS[args.config]
-    C, BPS, RATE, MAX_LPC, MAX_PO = cfg["ch"], cfg["bps"], cfg["rate"], cfg["lpc"], cfg["po"]
-    F = args.frames
-    pcm = make_pcm(1000 + 16 * args.config + rank, F, C, BPS)   # every rank encodes its own frame range
-    d_pcm = torch.from_numpy(pcm).cuda()
-    first_frame = rank * F                          # contiguous frame ranges per GPU (8(e))
-    # Multi-buffering, as a streaming encoder runs: consecutive batches rotate through a few
-    # encoder contexts (each with its own plans / output buffer in HBM) on their own HIP streams,
-    # so the HBM-bound, latency-bound and VALU-bound kernels of neighbouring batches overlap; a
-    # context's output stays valid until the context is used again.  --contexts 1 runs every
-    # batch back to back on one context.
-    ans = [GpuAnalyzer(BLOCK, MAX_PO, MAX_LPC, True, True, 2, 0.5, BPS, C, max_frames=F, device=local_rank)
-           for _ in range(args.contexts)]
-    an = ans[0]
-    if args.lag_split:
-        for a in ans:
-            a.set_tuning(a.TUNE_LAG_SPLIT, args.lag_split)
-    streams = [torch.cuda.Stream() for _ in ans]
-    step_no = [0]
+    C, BPS, RATE, MAX_LPC = cfg["ch"], cfg["bps"], cfg["rate"], cfg["lpc"]
+    strong = args.scaling == "strong"
+    whole = None
+    if strong:
+        # ONE stream of --frames frames; this rank encodes the contiguous range [lo, hi) with the frame numbers
+        # the whole stream gives them (every rank generates the same synthetic stream and takes its range)
+        lo, hi = shard_range(args.frames, world, rank)
+        whole = make_pcm(1000 + 16 * args.config, args.frames, C, BPS)
+        F, first_frame = hi - lo, lo
+        if F == 0:
+            sys.stderr.write(f"bench.py: rank {rank} got no frames ({args.frames} frames over {world} ranks)\n")
+            sys.exit(2)
+        w = Workload(torch, args.config, F, first_frame, args.contexts, local_rank, 0, args.lag_split,
+                     pcm=whole[lo * BLOCK * C: hi * BLOCK * C])
+        total_frames = args.frames
+    else:
+        F, first_frame = args.frames, rank * args.frames      # contiguous frame ranges per GPU (8(e))
+        w = Workload(torch, args.config, F, first_frame, args.contexts, local_rank, rank, args.lag_split)
+        total_frames = F * world
+    an = w.ans[0]
 
-    def step():   # analysis + frame assembly of one whole batch (flacgpu_encode_device)
-        i = step_no[0] % len(ans)
-        step_no[0] += 1
-        ans[i].encode_device(d_pcm.data_ptr(), F, BLOCK, first_frame, RATE, stream=streams[i].cuda_stream)
-
-    def timed(k):
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            step()
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
-
-    t_pre = time.perf_counter()
-    prewarm_steps = 0
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(8):
-            step()
-        torch.cuda.synchronize()
-        prewarm_steps += 8
+    prewarm_steps = w.prewarm(args.prewarm_ms)
     for _ in range(args.warmup):
-        step()
-    elapsed = timed(args.steps)
-    samples_per_step = F * BLOCK * C * world
+        w.step()
+    elapsed = w.timed(args.steps, dist)
+    samples_per_step = total_frames * BLOCK * C
     value = samples_per_step * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     sustained = None
     if args.sustained_steps > 0:
-        el = timed(args.sustained_steps)
+        el = w.timed(args.sustained_steps, dist)
         sustained = {"steps": args.sustained_steps, "ms_per_step": round(el / args.sustained_steps * 1e3, 4),
                      "value": round(samples_per_step * args.sustained_steps / el / 1e6, 2), "unit": "Msamples/s"}
+    # A/B of the input buffers and of the context count (same run, same clocks)
+    variants = {}
+    if not strong and len(w.ans) > 1:
+        w.same_buffer = True
+        el = w.timed(args.steps, dist)
+        w.same_buffer = False
+        variants["every_context_reads_one_buffer"] = {
+            "ms_per_step": round(el / args.steps * 1e3, 4),
+            "note": "what the r02 bench timed: all contexts re-read the same 256 MiB (an Infinity Cache of 256 MB under it); "
+                    "`value` is measured with one buffer per context"}
+    w.only_first = True
+    el = w.timed(args.steps, dist)
+    w.only_first = False
+    one_ctx_ms = el / args.steps * 1e3
+    variants["one_context_back_to_back"] = {"ms_per_step": round(one_ctx_ms, 4)}
     # per-shard counters (frames, bytes, min/max frame size) gathered over RCCL: the only
     # cross-GPU exchange of the path (seek-table offsets / STREAMINFO)
     counters = gather_shard_counters(an, F, dist)
 
-    # ---- parity precondition on this very batch, on EVERY rank: all distinct frames
+    # ---- parity precondition on this very batch, on EVERY rank and EVERY context: all distinct frames
     # byte-identical to the oracle, every frame of the batch round-tripped on the device
     import _oracle as orc
-    from _compare import orc_options_for
 
-    data, off = an.fetch_frames(F)
-    oopts = orc_options_for(BLOCK, MAX_PO, MAX_LPC, True, True)
-    check = min(DISTINCT, F)
-    ok = 1
-    frames_differ = 0
-    for f in range(check):
-        planar = np.ascontiguousarray(pcm[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
-        rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=first_frame + f)
-        if rc != 0 or data[off[f]:off[f + 1]] != fb:
-            frames_differ += 1
-            if args.experiment:
-                continue
-            sys.stderr.write(f"rank {rank}: frame {f} differs from the oracle\n")
-            ok = 0
-            break
+    ok, identical, differ, compressed_bytes, verify = w.parity(orc, experiment=bool(args.experiment))
     st = an.stats()
     if st.order_ties:
         sys.stderr.write(f"rank {rank}: {st.order_ties} candidates inside the libm-sensitive order band\n")
-    an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
-    an.pack_device(first_frame, RATE)
-    vres, vms = an.verify_device(RATE, first_frame)
-    if (vres.bad_structure, vres.bad_crc16, vres.frames_pcm_differs) != (0, 0, 0):
-        ok = 0
+    okv = 1 if ok else 0
     if dist:
-        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        t = torch.tensor([okv], dtype=torch.int32, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        ok = int(t.item())
-    assert ok == 1, "parity check failed on at least one rank"
-    compressed_bytes = off[F]
+        okv = int(t.item())
+    assert okv == 1, "parity check failed on at least one rank"
+
+    emitted = None
+    if strong and args.emit_flac:
+        # the stream itself: frames of the last batch gathered to rank 0, metadata from the gathered sizes
+        from flac_codec_amd.encode import Options
+        from flac_codec_amd.parallel import finish_sharded_stream
+
+        data, off = an.fetch_frames(F)
+        o = Options.best() if cfg["lpc"] >= 12 else Options.default()
+        o = o.max_lpc_order(cfg["lpc"] or None).max_partition_order(cfg["po"])
+        flac = finish_sharded_stream(bytes(data[: off[F]]), [off[i + 1] - off[i] for i in range(F)], whole, o, RATE, BPS, C,
+                                     dist)
+        if rank == 0:
+            with open(args.emit_flac, "wb") as fh:
+                fh.write(flac)
+            emitted = {"path": args.emit_flac, "bytes": len(flac)}
 
     out = None
     if rank == 0:
         analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties,
                           "order_ties_resolved_on_host": st.order_ties_resolved, "log2_edge": st.log2_edge,
                           "candidates": (4 if C == 2 else C) * F}
-        verify = {"kernel_ms": round(vms, 3), "frames": vres.frames, "compared_pcm": bool(vres.compared_pcm),
-                  "Msamples/s": round(F * BLOCK * C / (vms * 1e-3) / 1e6, 1)}
-        # ---- per-kernel durations (HIP events on the launch stream), extra timed passes
-        an.set_timing(True)
-        reps = 5
-        acc = {}
-        for _ in range(reps):
-            an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
-            ms_a = an.kernel_ms()
-            an.pack_device(first_frame, RATE)
-            ms_b = an.kernel_ms()
-            for k, v in {**ms_a, **ms_b}.items():
-                acc[k] = acc.get(k, 0.0) + v / reps
-        an.set_timing(False)
+        kernels, dom, alg = w.kernels_report(compressed_bytes)
+        sum_kernels = sum(v["ms"] for v in kernels.values())
+        variants["one_context_back_to_back"]["sum_of_kernel_ms"] = round(sum_kernels, 4)
+        variants["one_context_back_to_back"]["sum_over_step"] = round(sum_kernels / one_ctx_ms, 4)
         mfma_exp = None
-        if 1 <= MAX_LPC <= 16 and C == 2:
+        if 1 <= MAX_LPC <= 16 and C == 2 and not strong:
             # experiment: the same autocorrelation on the f64 matrix cores (NOT bit-exact, not used)
-            an.analyze_device(d_pcm.data_ptr(), F, BLOCK)
+            an.analyze_device(w.d_pcm[0].data_ptr(), F, BLOCK)
             mf = an.experiment_mfma_autocorr()
             issued = 4 * F * (BLOCK // 64) * 2 * 2048.0       # MFMAs x 2048 flop (16x16x4 f64)
             mfma_exp = {"kernel": "k_autocorr_mfma", "ms": round(mf["ms"], 4),
@@ -463,78 +722,34 @@ def main():
                         "candidates_compared": mf["compared"],
                         "candidates_whose_quantised_lpc_params_change": mf["params_differ"],
                         "note": "re-associated sums are not the reference's left fold; kept off the product path"}
-        n_cand = (4 if C == 2 else C) * F          # L, R, M, S per stereo frame; one per channel otherwise
-        cand_samples = n_cand * BLOCK
-        # algorithmic bytes / flops per launch (DESIGN.md "Kernels"); only kernels
-        # that were launched on this workload appear
-        alg = {
-            "k_deinterleave": ("hbm", 8.0 * F * BLOCK * C),
-            "k_autocorr": ("f64", 2.0 * BLOCK * (MAX_LPC + 1) * n_cand),
-            # fused FIXED + LPC + Rice search: every candidate's samples are read once, residuals
-            # never leave registers, 280-byte plan out
-            "k_cand64": ("hbm", 4.0 * cand_samples + 280.0 * n_cand),
-            # k_frame64 (reported in the k_pack slot): samples in, finished frame bytes out
-            "k_pack": ("hbm", 4.0 * F * BLOCK * C + compressed_bytes),
-        }
-        kernels = {}
-        for k, ms in acc.items():
-            if ms <= 0:
-                continue
-            entry = {"ms": round(ms, 4)}
-            if k in alg:
-                kind, amount = alg[k]
-                if kind == "hbm":
-                    entry["GB/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
-                else:
-                    entry["GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
-            kernels[k] = entry
-        hbm_kernels = {k: v for k, v in kernels.items() if "GB/s" in v}
-        dom = max(hbm_kernels, key=lambda k: hbm_kernels[k]["ms"])
-        achieved = hbm_kernels[dom]["GB/s"]
-        # HBM bytes and VALU instructions per launch of the dominant kernel come from the committed
-        # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh; corrected as
-        # MI355X_MICROARCH.md prescribes); they are deterministic for a given input and workload
-        names = {"k_autocorr": "k_autocorr4", "k_deinterleave": "k_deinterleave2", "k_pack": "k_frame64"}
-        traffic = traffic_src = None
-        valu = None
-        if F == FRAMES and args.config == 3:
-            try:
-                key = names.get(dom, dom)
-                prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-                t = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
-                if key + "p" in t:      # the persistent variant of the kernel (k_cand64p)
-                    key += "p"
-                if key in t:
-                    traffic = t[key]["hbm_bytes"]
-                    traffic_src = {"source": "profiles/" + prof[-1], "kernel": key,
-                                   "fetch_bytes": t[key].get("fetch_bytes"), "write_bytes": t[key].get("write_bytes")}
-                vprof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_valu.json"))
-                vt = json.load(open(os.path.join(ROOT, "profiles", vprof[-1])))
-                if key in vt and vt[key].get("SQ_INSTS_VALU"):
-                    insts = vt[key]["SQ_INSTS_VALU"]
-                    valu = {"wave_insts_per_launch": insts, "source": "profiles/" + vprof[-1],
-                            "achieved_Ginst/s": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / 1e9, 1),
-                            "peak_Ginst/s": round(VALU_ISSUE_PEAK / 1e9, 1),
-                            "frac": round(insts / (hbm_kernels[dom]["ms"] * 1e-3) / VALU_ISSUE_PEAK, 4),
-                            "valu_active_per_wave_cycle": vt[key].get("valu_active_per_wave_cycle")}
-            except Exception:
-                pass
+        achieved = kernels[dom]["GB/s"]
+        traffic = traffic_src = valu = None
+        if F == FRAMES:
+            traffic, traffic_src, valu = profile_figures(args.config, dom, kernels[dom]["ms"])
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": hbm_kernels[dom]["ms"]}
+                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": kernels[dom]["ms"]}
         if valu:
             # the integer kernels are bound by VALU instruction issue, not by HBM
             roofline["valu_issue"] = valu
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(orc, cfg, pcm, F)
+            cpu = cpu_baseline(orc, cfg, w.pcm[0], F)
         e2e = None
         if world == 1 and not args.no_end_to_end:
-            e2e = end_to_end(cfg, pcm, local_rank, orc, args.e2e_batch_frames)
+            e2e = end_to_end(cfg, w.pcm[0], local_rank, orc, args.e2e_batch_frames)
+        pcm0 = w.pcm[0]
+        w.close()
+        others = None
+        if world == 1 and not args.no_other_configs and not args.experiment and args.frames == FRAMES:
+            others = {}
+            for cid in sorted(CONFIGS):
+                if cid != args.config:
+                    others[f"config{cid}"] = measure_other_config(torch, cid, args, local_rank, orc)
         out = {
-            "metric": "Msamples/s encode at level 8, 48kHz/24-bit stereo; bit-exact vs reference",
+            "metric": metric_text(args.config, differ == 0),
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -542,34 +757,42 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "i32/i64 (+f64 LPC analysis)",
             "data": "synthetic",
-            "config": {"workload": f"config {args.config}: {cfg['text']}; {F} frames per GPU per step, PCM "
-                                   f"resident in HBM, frame bytes produced in HBM; consecutive batches rotate "
-                                   f"through {len(ans)} encoder context(s) on separate HIP streams",
+            "config": {"workload": f"config {args.config}: {cfg['text']}; "
+                                   + (f"ONE stream of {total_frames} frames per step cut into contiguous frame ranges over "
+                                      f"{world} rank(s)" if strong else f"{F} frames per GPU per step")
+                                   + f", PCM resident in HBM, frame bytes produced in HBM; consecutive batches rotate "
+                                     f"through {len(w.ans)} encoder context(s) on separate HIP streams, each reading its "
+                                     f"own input buffer",
                        "baseline_config": args.config, "level": cfg["level"],
-                       "frames_per_gpu": F, "parallelism": f"frame ranges x{world}",
-                       "contexts": len(ans),
+                       "frames_per_gpu": F, "frames_per_step": total_frames, "parallelism": f"frame ranges x{world}",
+                       "contexts": len(w.ans), "distinct_input_buffers": len(w.ans) if not strong else 1,
                        "prewarm": f"{prewarm_steps} untimed steps ({args.prewarm_ms:.0f} ms) before the warm-up"},
             "sustained": sustained,
+            "variants": variants,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "end_to_end": e2e,
+            "other_configs": others,
             "kernels": kernels,
             "mfma_autocorr_experiment": mfma_exp,
             "device_verify": verify,
             "compression_ratio": round(compressed_bytes / (F * BLOCK * C * ((BPS + 7) // 8)), 4),
             "hbm_bound_fraction": round((8.0 * samples_per_step / world) / (ms_per_step * 1e-3) / 8e12, 4),
             "experiment": args.experiment,
-            "parity": {"frames_byte_identical_to_oracle_per_rank": check - frames_differ, "distinct_frames_in_batch": check,
-                       "frames_round_tripped_on_device_per_rank": F, "ranks_checked": world},
+            "parity": {"frames_byte_identical_to_oracle_per_rank": identical, "frames_checked_per_rank": identical + differ,
+                       "contexts_checked": len(w.ans),
+                       "frames_round_tripped_on_device_per_rank": F * len(w.ans), "ranks_checked": world},
             "analysis_stats": analysis_stats,
             "shard_counters": counters,
+            "emitted_stream": emitted,
         }
-    for a in ans:
-        a.close()
+        del pcm0
+    else:
+        w.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

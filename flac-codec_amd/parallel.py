@@ -123,7 +123,24 @@ def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, 
             f += take
         an.close()
     mine = b"".join(chunks)
-    local = [hi - lo, len(mine), min(sizes) if sizes else 0, max(sizes) if sizes else 0]
+    return finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sample, channels, dist)
+
+
+def finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sample, channels, dist=None):
+    """The exchange + assembly half of `encode_stream_sharded`: every rank passes the finished frame bytes of ITS
+    contiguous frame range (`mine`, with the per-frame `sizes`), rank 0 -- which owns the whole input `pcm` --
+    gets the .flac back, the others None.  Used by bench.py --scaling strong (frames encoded by the timed loop)."""
+    import hashlib
+
+    import numpy as np
+
+    from . import encode as E
+
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    co = options._c_options()
+    B, C = co.block_size, channels
+    local = [len(sizes), len(mine), min(sizes) if sizes else 0, max(sizes) if sizes else 0]
     per_rank = all_gather_counters(local, dist)
     merged = merge_counters([c for c in per_rank if c[0]] or per_rank)
     if world > 1:
@@ -149,7 +166,11 @@ def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, 
             body.append(bytes(gby[r][: c[1]].cpu().numpy().tobytes()))
         body = b"".join(body)
     else:
-        all_sizes, body = sizes, mine
+        all_sizes, body = list(sizes), mine
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    total_pcm = pcm.size // C
+    n_frames = (total_pcm + B - 1) // B
+    last_len = total_pcm - (n_frames - 1) * B
     assert len(all_sizes) == n_frames and sum(all_sizes) == len(body) == merged["total_bytes"]
     # the owner: MD5 over the little-endian ceil(bps/8)-byte samples of the whole stream
     width = (bits_per_sample + 7) // 8

@@ -9,8 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 "$@" > $OUT/stats.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 "$@" > $OUT/valu.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 --no-other-configs "$@" > $OUT/stats.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 --no-other-configs "$@" > $OUT/valu.log 2>&1
 cd $ROOT
 python3 - $OUT <<'PY'
 import csv,glob,sys,collections
