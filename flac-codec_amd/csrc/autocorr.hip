@@ -23,8 +23,12 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
     const bool private_tiles = kn.ac_private;  // previous kernel (A/B runs)
     if constexpr (STEREO) {
         if (p.inter) {   // interleaved input read in place (the host selects this only with the 4-way split)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
-                               frame0, nframes, n, win);
+            if (kn.ac_eight_waves && NL == 13)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<13, 8, true, true>), dim3(groups), dim3(512), 0, st, p,
+                                   frame0, nframes, n, win);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
+                                   frame0, nframes, n, win);
             return;
         }
     }

@@ -65,6 +65,7 @@ Knobs read_knobs() {
     k.no_fork = on("FLACGPU_NO_FORK");
     k.lpc_dyn = on("FLACGPU_LPC_DYN");
     k.cand_split = on("FLACGPU_CAND_SPLIT");
+    k.ac_eight_waves = on("FLACGPU_AC_WAVES8");
     if (const char *e = getenv("FLACGPU_CAND_GRID")) k.cand_grid = (uint32_t)atoi(e);
     const char *t = getenv("FLACGPU_TEST_KNOBS");
     if (t && t[0] == '1') {

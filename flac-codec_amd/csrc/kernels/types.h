@@ -130,7 +130,8 @@ __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_
 // when FLACGPU_TEST_KNOBS=1 is set as well.
 struct Knobs {
     bool no_direct = false, no_fast = false, no_w64 = false, no_persist = false, no_ac3 = false, ac_private = false,
-         no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false;
+         no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false,
+         ac_eight_waves = false;   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;
