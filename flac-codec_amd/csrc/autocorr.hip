@@ -32,6 +32,20 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
             return;
         }
     }
+    if constexpr (!STEREO) {
+        if (p.split_src) {   // interleaved independent channels: the producers split them on the way (no K0 pass)
+            if (p.channels == 8)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, 8>), dim3(groups), dim3(256), 0, st, p,
+                                   frame0, nframes, n, win);
+            else if (p.channels == 4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, 4>), dim3(groups), dim3(256), 0, st, p,
+                                   frame0, nframes, n, win);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true>), dim3(groups), dim3(256), 0, st, p,
+                                   frame0, nframes, n, win);
+            return;
+        }
+    }
     if (!private_tiles) {  // shared conversion through LDS
         if (p.ac_split == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,

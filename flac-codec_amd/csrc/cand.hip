@@ -25,7 +25,11 @@ bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 32, false>), dim3(grid), dim3(WG), 0, st, p);
         return stereo;
     }
-    if (!no_persist && B == FN && p.max_lpc_order <= 16) {
+    // independent channels (mono, 3..8 channels, wide stereo): the persistent kernel's four 16 KB rows per workgroup
+    // allow two workgroups per CU; k_cand64<64, 16, false> (152 VGPRs, no LDS) runs three waves per SIMD and is faster
+    // (config 4: 0.50 -> 0.33 ms per batch).  FLACGPU_CAND_PERSIST_N=1 brings the persistent one back for A/B runs.
+    const bool stereo_cands = p.stereo4 && p.ncand == 4;
+    if (!no_persist && B == FN && p.max_lpc_order <= 16 && (stereo_cands || kn.cand_persist_n)) {
         const bool stereo = p.stereo4 && p.ncand == 4;
         // default: three workgroups per CU for the stereo kernel (165 VGPRs, 32 KB of LDS), two for independent
         // channels (four 16 KB rows per workgroup)
@@ -37,6 +41,10 @@ bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks
     }
     if (p.max_lpc_order > 16) {  // orders 17..32: 4096-sample blocks only
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 32>), dim3(blocks), dim3(WG), 0, st, p);
+        return false;
+    }
+    if (B == FN && !p.stereo4) {   // independent channels: the instantiation without mid / side
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false>), dim3(blocks), dim3(WG), 0, st, p);
         return false;
     }
     switch (B) {

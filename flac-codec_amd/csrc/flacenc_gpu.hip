@@ -66,6 +66,7 @@ Knobs read_knobs() {
     k.lpc_dyn = on("FLACGPU_LPC_DYN");
     k.cand_split = on("FLACGPU_CAND_SPLIT");
     k.ac_eight_waves = on("FLACGPU_AC_WAVES8");
+    k.cand_persist_n = on("FLACGPU_CAND_PERSIST_N");
     if (const char *e = getenv("FLACGPU_CAND_GRID")) k.cand_grid = (uint32_t)atoi(e);
     const char *t = getenv("FLACGPU_TEST_KNOBS");
     if (t && t[0] == '1') {
@@ -529,6 +530,8 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.ac_split = (uint32_t)c->lag_split;
     p.planar = c->d_planar;
     p.inter = nullptr;
+    p.split_src = nullptr;
+    p.split_dst = nullptr;
     p.window_full = c->d_window_full;
     p.window_last = c->d_window_last;
     p.log2_thr = c->d_log2_thr;
@@ -668,9 +671,21 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // (one channel: interleaved and planar are the same bytes -- no copy either)
     const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
                                last_len == B && !c->knobs.no_direct;
-    if (!direct) begin(0);
-    bool have_orbits = direct;
-    if (direct) {
+    // Independent channels, interleaved, with LPC: k_autocorr4's producers split the batch into the planar rows while
+    // they read it (Params::split_src) -- the K0 pass (8 B per sample at the HBM roofline) disappears.  Needs every
+    // frame on the wave kernels (no generic-path frame reads the rows before the autocorrelation has written them).
+    const bool split = !direct && !packed_bytes && layout == FLACGPU_LAYOUT_INTERLEAVED && !c->stereo4 &&
+                       c->channels >= 2 && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 &&
+                       B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
+                       !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
+                         c->knobs.ac_private || c->knobs.experiment_mfma_ac);
+    if (split) {
+        p.split_src = d_pcm;
+        p.split_dst = c->d_planar;
+    }
+    if (!direct && !split) begin(0);
+    bool have_orbits = direct || split;
+    if (direct || split) {
     } else if (packed_bytes) {
         launch_k0_packed(c, packed_bytes, n_frames, last_len, st);
         have_orbits = true;
@@ -687,7 +702,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         if (direct) hipLaunchKernelGGL(k_stereo_stats_t<true>, dim3(n_frames), dim3(WG), 0, st, p);
         else hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(n_frames), dim3(WG), 0, st, p);
     }
-    if (!direct)
+    if (!direct && !split)
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, p, c->d_orbits,
                            c->abs_valid ? c->d_abs : nullptr);
     // blocks of exactly 4096 samples take the register-resident kernels; anything else (other

@@ -70,6 +70,10 @@ struct Params {
     // samples) read by k_autocorr4 / k_cand64p / k_frame64 themselves -- no K0 split, `planar` is not
     // written.  nullptr: the kernels read `planar`
     const int32_t *inter;
+    // SPLIT input: a batch of interleaved INDEPENDENT channels ([frame][sample][channel]) that k_autocorr4's producers
+    // split into the planar rows (split_dst = `planar`) while they read it -- no k_deinterleave_n pass; nullptr: not used
+    const int32_t *split_src;
+    int32_t *split_dst;
     const double *window_full, *window_last;
     const double *log2_thr;                        // [128], index e + 64
     CandInfo *cinfo;
@@ -131,7 +135,8 @@ __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_
 struct Knobs {
     bool no_direct = false, no_fast = false, no_w64 = false, no_persist = false, no_ac3 = false, ac_private = false,
          no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false,
-         ac_eight_waves = false;   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
+         ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
+         cand_persist_n = false;   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;
