@@ -1012,6 +1012,7 @@ int flacgpu_set_tuning(flacgpu_ctx *c, int key, int value) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     switch (key) {
     case FLACGPU_TUNE_TWO_RANGES: c->two_ranges = value != 0; return FLACGPU_OK;
+    case FLACGPU_TUNE_COPY_INPUT: c->knobs.no_direct = value != 0; return FLACGPU_OK;
     case FLACGPU_TUNE_LAG_SPLIT:
         if (value != 2 && value != 4) break;
         c->lag_split = value;

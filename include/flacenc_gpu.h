@@ -166,7 +166,8 @@ int flacgpu_analyze(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n
  * context keeps no copy (no K0 split pass; this is what the reference's `write(&[i32])` hands over,
  * encode.rs:558).  The buffer must therefore stay valid and unchanged until the batch's results have
  * been fetched (flacgpu_fetch* / flacgpu_verify_device / flacgpu_pack_device included) or the next
- * batch is submitted to this context.  FLACGPU_NO_DIRECT=1 in the environment restores the copy. */
+ * batch is submitted to this context.  flacgpu_set_tuning(ctx, FLACGPU_TUNE_COPY_INPUT, 1) (or FLACGPU_NO_DIRECT=1
+ * in the environment) restores the copy and with it the old rule: free once the submitted work has run. */
 int flacgpu_analyze_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,
                            uint32_t last_frame_len, void *stream);
 /* Copy the results of the last flacgpu_analyze_device to host buffers (any may be NULL). */
@@ -209,7 +210,13 @@ enum {
      * event (50-200 us) instead of spinning in hipEventSynchronize.  For processes with more waiting threads
      * than CPUs (many concurrent writers): a spinning waiter burns the CPU time the others -- and the MD5
      * engines -- need.  0 (default) spins (lowest latency). */
-    FLACGPU_TUNE_BLOCKING_WAIT = 3
+    FLACGPU_TUNE_BLOCKING_WAIT = 3,
+    /* 1: the context copies (splits) every batch of flacgpu_analyze_device / flacgpu_encode_device into its own
+     * planar buffer at submission, as before r02: d_pcm may be refilled as soon as the submitted work has run,
+     * whatever is fetched later (an LPC order tie re-decided at fetch time, flacgpu_verify_device, residual rows
+     * all work from the copy).  0 (default): direct input, the lifetime rule at flacgpu_analyze_device applies.
+     * For streaming callers that recycle one input buffer without waiting for their fetch. */
+    FLACGPU_TUNE_COPY_INPUT = 4
 };
 int flacgpu_set_tuning(flacgpu_ctx *ctx, int key, int value);
 int flacgpu_encode_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,

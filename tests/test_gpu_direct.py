@@ -147,6 +147,72 @@ def test_device_buffer_input(monkeypatch):
     an.close()
 
 
+def test_copy_input_tuning_frees_the_callers_buffer(monkeypatch):
+    """FLACGPU_TUNE_COPY_INPUT: the context works from its own copy, so a streaming caller may refill its device
+    buffer as soon as the submitted work has run -- the frames fetched, the residual rows and the device round trip
+    afterwards are still those of the batch that was submitted (the direct input's lifetime rule)."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+    n = 12
+    pcm = synth_fast(931, 2, 24, B * n)
+    try:
+        d = torch.from_numpy(pcm).cuda()
+    except RuntimeError as e:
+        pytest.skip(f"torch cannot use the GPU here: {e}")
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=n)
+    an.set_tuning(an.TUNE_COPY_INPUT, 1)
+    an.encode_device(d.data_ptr(), n, B, 3, 48000)
+    torch.cuda.synchronize()
+    d.random_(-(1 << 23), 1 << 23)        # the caller recycles its buffer
+    torch.cuda.synchronize()
+    data, off = an.fetch_frames(n)
+    oopts = orc_options_for(B, 6, 12, True, True)
+    for f, planar in enumerate(planar_frames(pcm, 2, B)):
+        rc, fb, _ = orc.encode_frame(oopts, 48000, 24, planar, frame_number=3 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f
+    res, _ = an.verify_device(48000, 3)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+    an.close()
+
+
+def test_independent_channels_split_inside_the_autocorrelation(monkeypatch):
+    """3 / 4 / 8 interleaved independent channels with LPC: k_autocorr4's producers split the batch into the planar
+    rows themselves (no k_deinterleave_n launch); same bytes as the K0 path and as the oracle, different wasted bits
+    per channel, an all-zero channel and a rail-DC channel included."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    for ch, bps, seed in ((8, 24, 950), (4, 16, 951), (3, 24, 952), (6, 20, 953)):
+        n = 5
+        x = synth_fast(seed, ch, bps, B * n).reshape(-1, ch).astype(np.int64)
+        x[:, 0] = (x[:, 0] >> 3) << 3                       # three wasted bits on channel 0
+        x[B:2 * B, 1] = 0                                   # an all-zero channel in frame 1
+        x[2 * B:3 * B, ch - 1] = (1 << (bps - 1)) - 1      # rail DC in frame 2
+        pcm = np.ascontiguousarray(x.astype(np.int32).reshape(-1))
+        outs = {}
+        for direct in (True, False):
+            if direct:
+                monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+            else:
+                monkeypatch.setenv("FLACGPU_NO_DIRECT", "1")
+            an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=n)
+            data, off = an.encode_frames(pcm, n, B, 11, 96000)
+            an.set_timing(True)
+            an.analyze(pcm, n, B)
+            ms = {k: v for k, v in an.kernel_ms().items() if v > 0}
+            an.close()
+            outs[direct] = (data, off)
+            assert ("k_deinterleave" in ms) == (not direct), (ch, direct, ms)
+        assert outs[True] == outs[False]
+        data, off = outs[True]
+        oopts = orc_options_for(B, 6, 12, True, True)
+        for f, planar in enumerate(planar_frames(pcm, ch, B)):
+            rc, fb, _ = orc.encode_frame(oopts, 96000, bps, planar, frame_number=11 + f)
+            assert rc == 0 and data[off[f]:off[f + 1]] == fb, (ch, f)
+
+
 def test_mono_is_read_in_place(monkeypatch):
     """One channel: the interleaved buffer is the planar row -- analysed without the K0 copy (an OR pass only)."""
     from flac_codec_amd.gpu import GpuAnalyzer
