@@ -778,14 +778,28 @@ struct flacenc_writer {
             const size_t count = (static_cast<size_t>(usable - 1) * B + ll) * C;
             const double t0 = now_ms();
             if (int rc = lane->reserve_in(static_cast<size_t>(batch_frames) * B * C * 4 + 64)) return rc;
-            pack_le(interleaved, count, upload_width, lane->pin_in);
-            stats.pack_ms += now_ms() - t0;
             // MD5 of the whole call's samples (the frame that trips ExcessiveTotalSamples included:
             // the reference hashes before it encodes, encode.rs:571-577)
             uint64_t ticket;
             if (upload_width == bytes_per_sample && usable == n_frames) {
-                ticket = md5_worker.push(lane->pin_in, count * bytes_per_sample);
+                // staged and handed to the MD5 chain piece by piece (runs of whole 64-byte blocks): the hash of a
+                // large batch starts after its first piece, not after the whole batch has been packed -- in a burst
+                // of many streams the chain's latency (one AVX-512 lane: ~0.5 GB/s) is what bounds the call
+                const size_t frame_bytes = static_cast<size_t>(B) * C * bytes_per_sample;
+                size_t piece_frames = 32;
+                while (piece_frames < usable && (piece_frames * frame_bytes) % 64) piece_frames *= 2;
+                if ((piece_frames * frame_bytes) % 64) piece_frames = usable;
+                ticket = 0;
+                for (size_t f0 = 0; f0 < usable; f0 += piece_frames) {
+                    const size_t f1 = std::min<size_t>(usable, f0 + piece_frames);
+                    const size_t s0 = f0 * B * C, s1 = (f1 == usable) ? count : f1 * B * C;
+                    pack_le(interleaved + s0, s1 - s0, upload_width, lane->pin_in + s0 * upload_width);
+                    ticket = md5_worker.push(lane->pin_in + s0 * bytes_per_sample, (s1 - s0) * bytes_per_sample);
+                }
+                stats.pack_ms += now_ms() - t0;
             } else {
+                pack_le(interleaved, count, upload_width, lane->pin_in);
+                stats.pack_ms += now_ms() - t0;
                 md5_worker.wait(md5_worker.pushed);   // keep the chain in stream order
                 md5_samples(interleaved, all_samples);
                 ticket = md5_worker.pushed;
