@@ -39,10 +39,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <mutex>
 #include <thread>
+#include <atomic>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -51,6 +53,12 @@ thread_local std::string g_last_error;
 
 // Every FLACGPU_* environment knob (kernels/types.h Knobs), read when a context is created.  The test-only knobs
 // are ignored unless FLACGPU_TEST_KNOBS=1 accompanies them: a production process cannot be skewed by a stray variable.
+static std::atomic<uint64_t> g_early_downloads{0}, g_early_remainders{0};
+// (experiment counters: early downloads queued / of them completed by a second copy of the remainder)
+extern "C" void flacgpu_early_download_counters(uint64_t *queued, uint64_t *with_remainder) {
+    if (queued) *queued = g_early_downloads.load();
+    if (with_remainder) *with_remainder = g_early_remainders.load();
+}
 Knobs read_knobs() {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
@@ -67,6 +75,7 @@ Knobs read_knobs() {
     k.cand_split = on("FLACGPU_CAND_SPLIT");
     k.ac_eight_waves = on("FLACGPU_AC_WAVES8");
     k.cand_persist_n = on("FLACGPU_CAND_PERSIST_N");
+    k.early_download = on("FLACGPU_EARLY_DOWNLOAD");
     if (const char *e = getenv("FLACGPU_CAND_GRID")) k.cand_grid = (uint32_t)atoi(e);
     const char *t = getenv("FLACGPU_TEST_KNOBS");
     if (t && t[0] == '1') {
@@ -144,6 +153,10 @@ struct flacgpu_ctx {
     uint64_t *h_off = nullptr;          // pinned: byte offsets of the frames of the batch in flight
     hipEvent_t ev_sizes = nullptr, ev_bytes = nullptr, ev_null = nullptr;
     bool sizes_pending = false, bytes_pending = false;
+    // early download (FLACGPU_EARLY_DOWNLOAD): a copy of the previous batch's size (+ margin) queued right behind the
+    // packing kernels, before this batch's sizes are known; the remainder (if any) follows once they are
+    uint64_t prev_total = 0, early_bytes = 0;
+    uint8_t *early_dst = nullptr;
     // last call
     uint32_t last_frames = 0, last_len = 0;
     bool timing = false;
@@ -1522,6 +1535,17 @@ int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint
     // frames written straight to the host buffer: they are there when the stream has drained
     if (c->out_in_host)
         if (int rc = record_waitable(c, c->ev_bytes, st)) return rc;
+    c->early_bytes = 0;
+    c->early_dst = nullptr;
+    if (!c->out_in_host && c->knobs.early_download && c->host_out && c->prev_total) {
+        const uint64_t guess = std::min<uint64_t>(std::min<uint64_t>(c->packed_cap, c->host_out_cap),
+                                                  c->prev_total + c->prev_total / 8 + 4096);
+        HIP_TRY(hipMemcpyAsync(c->host_out, c->d_packed, guess, hipMemcpyDeviceToHost, st));
+        if (int rc = record_waitable(c, c->ev_bytes, st)) return rc;
+        c->early_bytes = guess;
+        c->early_dst = c->host_out;
+        g_early_downloads.fetch_add(1, std::memory_order_relaxed);
+    }
     HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_layout, 0));
     HIP_TRY(hipMemcpyAsync(c->h_off, c->d_frame_off, sizeof(uint64_t) * ((size_t)n_frames + 1),
                            hipMemcpyDeviceToHost, c->aux_stream));
@@ -1572,6 +1596,18 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
         if (out != c->host_out) {
             if (int rc = wait_waitable(c, c->ev_bytes)) return rc;
             memcpy(out, c->host_out, bytes);
+        }
+        c->bytes_pending = true;
+        return FLACGPU_OK;
+    }
+    c->prev_total = bytes;
+    if (c->early_bytes && out == c->early_dst && c->ties_resolved == 0) {
+        // the early copy (queued behind the kernels at submission) holds the first early_bytes; the rest now
+        if (bytes > c->early_bytes) {
+            g_early_remainders.fetch_add(1, std::memory_order_relaxed);
+            HIP_TRY(hipMemcpyAsync(out + c->early_bytes, reinterpret_cast<const uint8_t *>(c->d_packed) + c->early_bytes,
+                                   bytes - c->early_bytes, hipMemcpyDeviceToHost, c->own_stream));
+            if (int rc = record_waitable(c, c->ev_bytes, c->own_stream)) return rc;
         }
         c->bytes_pending = true;
         return FLACGPU_OK;

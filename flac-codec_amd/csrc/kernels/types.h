@@ -136,7 +136,8 @@ struct Knobs {
     bool no_direct = false, no_fast = false, no_w64 = false, no_persist = false, no_ac3 = false, ac_private = false,
          no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false,
          ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
-         cand_persist_n = false;   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
+         cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
+         early_download = false;   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;

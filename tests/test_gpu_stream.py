@@ -293,3 +293,37 @@ print("ok")
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_early_download_of_batches_with_a_generic_path_frame(monkeypatch):
+    """FLACGPU_EARLY_DOWNLOAD=1: the frames' D2H copy is queued behind the packing kernels before the sizes are known
+    (the previous batch's size as the guess, the remainder afterwards).  r02 saw stale bytes from such a copy for
+    batches with a generic-path frame; the cause was on the host -- the lane's pinned destination was re-allocated when
+    the sizes arrived -- and the destination is now sized for the worst case BEFORE submission.  Many
+    concurrent writers on pooled lanes, every stream ending in a short (generic-path) frame, ragged lengths so that
+    guesses are too small as often as too large: every stream must be the oracle's."""
+    import ctypes
+
+    from flac_codec_amd import _lib
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    monkeypatch.setenv("FLACGPU_EARLY_DOWNLOAD", "1")
+    B = 4096
+    shapes = [((3 + (i * 7) % 19) * B + 1 + (i * 977) % (B - 1), 400 + i % 7) for i in range(48)]
+    streams = [synth_fast(seed, 2, 24, n) for n, seed in shapes]
+    refs = []
+    for s in streams:
+        rc, o, _ = orc.encode_stream(orc.options("best"), 48000, 24, 2, s, total_known=True)
+        assert rc == 0
+        refs.append(o)
+    # batch_frames 6 / depth 3: lanes of their own (the knob is read when a lane's context is created)
+    be = BatchEncoder(Options.best().batch_frames(6).pipeline_depth(3), threads=24)
+    q0, w0 = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _lib.lib().flacgpu_early_download_counters(ctypes.byref(q0), ctypes.byref(w0))
+    for r in range(6):
+        outs = be.encode(streams, 48000, 24, 2)
+        for k, o in enumerate(outs):
+            assert bytes(o) == refs[k], f"round {r} stream {k}"
+    q1, w1 = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _lib.lib().flacgpu_early_download_counters(ctypes.byref(q1), ctypes.byref(w1))
+    assert q1.value - q0.value >= 100 and w1.value > w0.value     # the path really ran, remainder copies included
