@@ -1429,7 +1429,13 @@ int flacgpu_decode_stream(const uint8_t *data, size_t len, int device, int32_t *
     launch_crc(true, pp, q, (uint32_t)F, (uint32_t *)b.counts, b.st);
     launch_decode_finish(pp, (int32_t *)b.pcm, nullptr, (uint32_t *)b.counts, b.st, (const uint32_t *)b.fn);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> planar(F * C * ldb);
+    std::vector<int32_t> planar;
+    try {   // sizes come from the (untrusted) stream's headers: an allocation failure is an error code, not an exception
+        planar.resize(F * C * ldb);
+    } catch (const std::bad_alloc &) {
+        g_last_error = "flacgpu_decode_stream: out of host memory for the decoded PCM";
+        return FLACGPU_ERR_UNSUPPORTED;
+    }
     uint32_t counts[4];
     HIP_TRY(hipMemcpyAsync(planar.data(), b.pcm, sizeof(int32_t) * planar.size(), hipMemcpyDeviceToHost, b.st));
     HIP_TRY(hipMemcpyAsync(counts, b.counts, sizeof counts, hipMemcpyDeviceToHost, b.st));

@@ -525,6 +525,9 @@ struct flacenc_writer {
     CtxKey gpu_key{};
     ~flacenc_writer() {
         for (auto &f : inflight) (void)flacgpu_wait(f.lane->gpu);   // nothing may still write into a pooled lane
+        // ... and nothing may still READ one: queued MD5 runs point at the lanes' pinned staging buffers (abandoned or
+        // failed streams reach this point with runs pending), which the next owner overwrites or the pool frees
+        md5_worker.wait(md5_worker.pushed);
         for (Lane *l : lanes) lane_pool().give(gpu_key, l);
     }
 
@@ -1215,6 +1218,19 @@ int flacenc_pack_frames(uint32_t sample_rate, uint32_t bps, uint32_t channels,
 // a time through FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) into the job's own
 // output buffer; the GPU is shared through the pooled lanes, the MD5 chains run on the writers'
 // worker threads.
+size_t flacenc_worst_case_bytes(const flacenc_options *opts, uint32_t bits_per_sample, uint32_t channels,
+                                uint64_t pcm_frames) {
+    if (!opts || opts->block_size == 0 || channels == 0) return 0;
+    const uint64_t B = opts->block_size;
+    const uint64_t frames = (pcm_frames + B - 1) / B + 1;
+    // a frame: header <= 16 bytes + CRC-16, every subframe VERBATIM (header byte + wasted-bits escape) at bps + 1 bits
+    // (a side channel), rounded up; one 18-byte seek point per frame at most; fLaC + STREAMINFO (4 + 38), block headers,
+    // the vendor comment and the padding
+    const uint64_t frame_bytes = 18 + channels * 2 + (B * channels * (bits_per_sample + 1) + 7) / 8;
+    const uint64_t meta = 42 + 3 * 4 + 64 + (opts->padding > 0 ? (uint64_t)opts->padding : 0);
+    return (size_t)(frames * (frame_bytes + 18) + meta + 64);
+}
+
 int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
     if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
     if (int e = options_error(*opts_in)) return e;

@@ -572,9 +572,12 @@ class BatchEncoder:
         L = _stream_lib()
         arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in streams]
         jobs = (_CJob * len(arrs))()
-        width = (bits_per_sample + 7) // 8
+        co = self._opts._c_options()
+        L.flacenc_worst_case_bytes.restype = C.c_size_t
+        L.flacenc_worst_case_bytes.argtypes = [C.POINTER(_COptions), C.c_uint32, C.c_uint32, C.c_uint64]
         for i, a in enumerate(arrs):
-            cap = a.size * width + a.size // 16 + (1 << 16)
+            # every frame VERBATIM with its headers + a seek point per frame + the metadata: never too small
+            cap = int(L.flacenc_worst_case_bytes(C.byref(co), bits_per_sample, channels, a.size // max(1, channels)))
             if i >= len(self._bufs):
                 self._bufs.append(np.empty(cap, dtype=np.uint8))
             elif self._bufs[i].size < cap:

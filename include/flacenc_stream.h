@@ -156,9 +156,13 @@ const uint8_t *flacenc_writer_data(flacenc_writer *w, size_t *len);
 /* Batch front end: many independent streams encoded concurrently by `threads` host workers (0 =
  * default), each one FlacSampleWriter::new(total known) / write / finalize (encode.rs:487, 558, 624)
  * with the .flac bytes written to the job's own buffer (FLACENC_ERR_IO in `status` when it is too
- * small; the PCM size at stream width plus the metadata is always enough).  The workers share the
+ * small; flacenc_worst_case_bytes() is always enough: every frame VERBATIM at bps + 1 bits with its headers, one seek
+ * point per frame, the metadata blocks).  The workers share the
  * GPU through the pooled analysis lanes; every stream's MD5 chain runs on a thread of its own.
  * Returns 0 or the first job's error. */
+/* Upper bound of the .flac size of a stream of `pcm_frames` samples per channel under `opts`. */
+size_t flacenc_worst_case_bytes(const flacenc_options *opts, uint32_t bits_per_sample, uint32_t channels,
+                                uint64_t pcm_frames);
 typedef struct {
     const int32_t *samples;   /* interleaved, the whole stream */
     size_t count;             /* samples over all channels */

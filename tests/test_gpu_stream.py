@@ -327,3 +327,21 @@ def test_early_download_of_batches_with_a_generic_path_frame(monkeypatch):
     q1, w1 = ctypes.c_uint64(0), ctypes.c_uint64(0)
     _lib.lib().flacgpu_early_download_counters(ctypes.byref(q1), ctypes.byref(w1))
     assert q1.value - q0.value >= 100 and w1.value > w0.value     # the path really ran, remainder copies included
+
+
+def test_batch_encoder_worst_case_buffers():
+    """flacenc_worst_case_bytes sizes BatchEncoder's output buffers: full-scale noise (every frame VERBATIM) at a small
+    block size, where frame headers, the bps + 1 side channel and one seek point per frame exceed the PCM size --
+    the case the former `PCM size + 1/16` rule failed with FLACENC_ERR_IO."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    rng = np.random.Generator(np.random.PCG64(91))
+    for bps, block in ((8, 192), (16, 256), (24, 4096)):
+        lo, hi = -(1 << (bps - 1)), (1 << (bps - 1))
+        streams = [rng.integers(lo, hi, size=2 * (block * 37 + 11), dtype=np.int64).astype(np.int32) for _ in range(3)]
+        opts = Options.best().block_size(block)
+        outs = BatchEncoder(opts, threads=3).encode(streams, 44100, bps, 2)
+        for s, o in zip(streams, outs):
+            rc, ref, _ = orc.encode_stream(orc.options("best").copy(block_size=block), 44100, bps, 2, s, total_known=True)
+            assert rc == 0 and o == ref
+            assert len(o) > s.size * ((bps + 7) // 8)      # really larger than the PCM at stream width
