@@ -325,15 +325,20 @@ struct LanePool {
         }
         return nullptr;
     }
+    // a full pool gives up its OLDEST idle lane (least recently returned) for the one coming back: a process that has
+    // moved on to other stream shapes keeps pooling the shapes it uses now (the r02 pool destroyed the newcomer instead,
+    // and every later stream of a new shape paid a context creation)
     void give(const CtxKey &k, Lane *l) {
+        Lane *evict = nullptr;
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (idle.size() < kPoolCap) {
-                idle.emplace_back(k, l);
-                return;
+            if (idle.size() >= kPoolCap) {
+                evict = idle.front().second;
+                idle.erase(idle.begin());
             }
+            idle.emplace_back(k, l);
         }
-        l->destroy();
+        if (evict) evict->destroy();
     }
 };
 LanePool &lane_pool() {

@@ -316,8 +316,9 @@ def test_early_download_of_batches_with_a_generic_path_frame(monkeypatch):
         rc, o, _ = orc.encode_stream(orc.options("best"), 48000, 24, 2, s, total_known=True)
         assert rc == 0
         refs.append(o)
-    # batch_frames 6 / depth 3: lanes of their own (the knob is read when a lane's context is created)
-    be = BatchEncoder(Options.best().batch_frames(6).pipeline_depth(3), threads=24)
+
+    # batch_frames 13: lanes no other test of this process has created (the knob is read when a lane's context is made)
+    be = BatchEncoder(Options.best().batch_frames(13).pipeline_depth(3), threads=24)
     q0, w0 = ctypes.c_uint64(0), ctypes.c_uint64(0)
     _lib.lib().flacgpu_early_download_counters(ctypes.byref(q0), ctypes.byref(w0))
     for r in range(6):
