@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <future>
 #include <cstdio>
 #include <cstring>
@@ -1059,6 +1060,58 @@ struct flacenc_writer {
     }
 };
 
+namespace {
+// Parked helper threads for flacenc_encode_many: run(k, fn) has k helpers execute fn() concurrently with the caller
+// (which runs it too) and returns when all of them are done.  Threads are created on demand and never exit (a
+// detached, intentionally leaked pool: no joins during static destruction).
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::function<void()> *> tasks;
+    unsigned idle = 0, total = 0;
+    static WorkerPool &get() {
+        static WorkerPool *p = new WorkerPool();
+        return *p;
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lock(mu);
+        for (;;) {
+            idle++;
+            cv_work.wait(lock, [&] { return !tasks.empty(); });
+            idle--;
+            std::function<void()> *t = tasks.front();
+            tasks.pop_front();
+            lock.unlock();
+            (*t)();
+            lock.lock();
+        }
+    }
+    template <class F>
+    void run(unsigned helpers, F &fn) {
+        std::atomic<unsigned> left{helpers};
+        std::mutex dm;
+        std::condition_variable dcv;
+        std::function<void()> task = [&] {
+            fn();
+            if (left.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> l(dm);
+                dcv.notify_all();
+            }
+        };
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (unsigned i = 0; i < helpers; i++) tasks.push_back(&task);
+            const unsigned need = helpers > idle ? helpers - idle : 0;
+            for (unsigned i = 0; i < need && total < 1024; i++, total++) std::thread([this] { worker(); }).detach();
+        }
+        cv_work.notify_all();
+        fn();
+        std::unique_lock<std::mutex> l(dm);
+        dcv.wait(l, [&] { return left.load() == 0; });
+    }
+};
+}  // namespace
+
 extern "C" {
 
 const char *flacenc_last_error(void) { return g_err.c_str(); }
@@ -1280,10 +1333,9 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned nt = threads ? threads : std::min<unsigned>(hw / 2 ? hw / 2 : 1, 64);
     nt = static_cast<unsigned>(std::min<size_t>(nt, std::max<size_t>(1, n_jobs)));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
+    // the helpers come from a process-wide pool of parked threads (creating 63 threads per call cost a 64-stream
+    // burst 2-3 ms before its last stream had even started)
+    WorkerPool::get().run(nt - 1, work);
     for (size_t i = 0; i < n_jobs; i++)
         if (jobs[i].status) return jobs[i].status;
     return 0;
