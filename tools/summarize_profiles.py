@@ -7,6 +7,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import shutil
 import sys
@@ -16,7 +17,7 @@ src = f"gpurun_out/{tag}"
 
 
 def per_kernel(counter_dir, counter):
-    files = glob.glob(f"{src}/{counter_dir}/*/*counter_collection.csv")
+    files = sorted(glob.glob(f"{src}/{counter_dir}/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]   # newest run only
     agg = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -50,7 +51,7 @@ for k, v in valu.items():
         v["valu_insts_per_wave"] = round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1)
 if valu:
     json.dump(valu, open(f"profiles/{tag}_valu.json", "w"), indent=1)
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")
+stats = sorted(glob.glob(f"{src}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]   # newest run only
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
 try:
