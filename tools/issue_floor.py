@@ -193,12 +193,12 @@ def main():
     A = lambda f: os.path.join(a.asm_dir, f)   # noqa: E731
     out = {"costs_ns_per_wave_inst_per_simd_at_4_waves": cost,
            "method": __doc__.split("usage:")[0].strip()}
-    # config 3: order-12 LPC (12 taps), fixed order 2 on this signal
+    # config 3: the bench signal takes LPC order 2 (2 taps) and fixed order 2
     cd = blocks_of(A("cand_direct.gfx950.s"), "k_cand64pILi64ELi16ELb1ELb1ELb0")
     ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1")
     fr = blocks_of(A("frame64_d.gfx950.s"), "k_frame64ILi128ELi64ELi16ELb1")
     out["config3"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 12, 2), cost, dyn("r03_d", "k_cand64p"), 32768),
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn("r03_d", "k_cand64p"), 32768),
         "k_autocorr": floor("k_autocorr4<13,4,true,true>", pick_loops(ac), cost, dyn("r03_d", "k_autocorr4")),
         "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn("r03_d", "k_frame64")),
     }
