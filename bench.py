@@ -456,7 +456,13 @@ class Workload:
                 entry["GB/s" if kind == "hbm" else "GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
             kernels[k] = entry
         hbm = {k: v for k, v in kernels.items() if "GB/s" in v}
-        dom = max(hbm, key=lambda k: hbm[k]["ms"])
+        # dominant kernel = the longest launch; launches within 3 % of it count as tied (run-to-run noise decides their
+        # order) and the tie goes to the one with the larger algorithmic traffic
+        longest = max(v["ms"] for v in hbm.values())
+        tied = [k for k, v in hbm.items() if v["ms"] >= 0.97 * longest]
+        dom = max(tied, key=lambda k: alg[k][1])
+        for k, v in hbm.items():
+            v["hbm_roofline_frac"] = round(v["GB/s"] / HBM_PEAK_GBS, 4)
         return kernels, dom, alg
 
     def close(self):
@@ -729,7 +735,9 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
-                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": kernels[dom]["ms"]}
+                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": kernels[dom]["ms"],
+                    "dominance_rule": "longest launch; launches within 3 % of it are tied and the larger algorithmic "
+                                      "traffic wins (every HBM-priced kernel's own fraction is in kernels.*.hbm_roofline_frac)"}
         if valu:
             # the integer kernels are bound by VALU instruction issue, not by HBM
             roofline["valu_issue"] = valu
