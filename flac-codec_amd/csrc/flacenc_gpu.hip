@@ -966,7 +966,8 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     // atomic OR at shared words) -> k_crc
     const uint32_t B = p.block_size;
     const bool narrow = (c->bps + (c->stereo4 ? 1u : 0u) <= 25u) && !c->knobs.no_fast;
-    const uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
+    uint32_t fbw = frame_fb_words(p.channels, c->bps, B);
+    if (c->stereo4 && p.exhaustive) fbw = std::min(fbw, frame_fb_words_exhaustive_stereo(c->bps, B));
     // wave per subframe: block lengths 64 x {16, 18, 32, 36, 64}; orders 17..32 and 5..8 channels
     // for 4096-sample blocks only (and not both)
     const bool f64w = narrow && wave_block_size(B) &&

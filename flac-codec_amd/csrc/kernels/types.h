@@ -125,6 +125,15 @@ __host__ __device__ constexpr uint32_t frame_fb_words(uint32_t channels, uint32_
 }
 
 
+// Stereo frames whose channel assignment is chosen EXHAUSTIVELY (first minimum of the candidate pairs' bit counts,
+// encode.rs:2747-2786): the chosen pair is never larger than L + R, and a chosen subframe never larger than its
+// VERBATIM form, so the frame body is bounded by two bps-bit VERBATIM subframes -- not by the bps + 1 bits of a side
+// channel.  For 24-bit stereo that is 24.6 KB instead of 25.6 KB of LDS per k_frame64 workgroup: six workgroups per
+// CU instead of five.  (The fast channel choice picks its pair before any bit count exists: frame_fb_words.)
+__host__ __device__ constexpr uint32_t frame_fb_words_exhaustive_stereo(uint32_t bps, uint32_t n = FN) {
+    return (((16u + 2u) * 8u + 2u * (n * bps + 64u) + 31u) / 32u + 2u + 3u) & ~3u;
+}
+
 // block lengths the wave kernels are instantiated for: 64 lanes x SPL samples
 #define FLACGPU_WAVE_SIZES(X) X(4096, 64) X(2304, 36) X(2048, 32) X(1152, 18) X(1024, 16)
 

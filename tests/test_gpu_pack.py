@@ -83,6 +83,26 @@ def test_verbatim_constant_wasted_escape():
     run_case(x, 1, 24, max_lpc=0)
 
 
+def test_largest_possible_stereo_frames():
+    """Full-scale noise, every subframe VERBATIM: the frames k_frame64 builds in its LDS bit string are as large as they
+    get.  With the exhaustive channel choice the LDS frame is sized for two bps-bit subframes (the chosen pair never
+    exceeds L + R: frame_fb_words_exhaustive_stereo); the fast choice picks its pair before any bit count exists and may
+    take a 25-bit side channel VERBATIM (frame_fb_words)."""
+    rng = np.random.Generator(np.random.PCG64(213))
+    for bps in (24, 16, 12):
+        lo, hi = -(1 << (bps - 1)), 1 << (bps - 1)
+        noise = rng.integers(lo, hi, size=4096 * 2 * 5, dtype=np.int64).astype(np.int32)
+        for exhaustive in (True, False):
+            run_case(noise, 2, bps, exhaustive=exhaustive)
+            run_case(noise, 2, bps, exhaustive=exhaustive, mid_side=False, max_lpc=0)
+    # anti-correlated rails: |side| needs bps + 1 bits on every sample
+    l = np.where(rng.integers(0, 2, size=4096 * 4) == 1, (1 << 23) - 1, -(1 << 23)).astype(np.int64)
+    r = -l - 1 + rng.integers(0, 2, size=l.size)
+    pcm = np.stack([l, np.clip(r, -(1 << 23), (1 << 23) - 1)], axis=1).astype(np.int32).reshape(-1)
+    for exhaustive in (True, False):
+        run_case(pcm, 2, 24, exhaustive=exhaustive)
+
+
 def test_block_sizes_and_short_tail():
     for bs in (16, 33, 192, 1152, 4608, 16384):
         run_case(synth_fast(210 + bs, 2, 16, bs * 2 + bs // 3), 2, 16, block_size=bs)
