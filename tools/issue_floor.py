@@ -198,9 +198,9 @@ def main():
     ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1")
     fr = blocks_of(A("frame64_d.gfx950.s"), "k_frame64ILi128ELi64ELi16ELb1")
     out["config3"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn("r03_e", "k_cand64p"), 32768),
-        "k_autocorr": floor("k_autocorr4<13,4,true,true>", pick_loops(ac), cost, dyn("r03_e", "k_autocorr4")),
-        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn("r03_e", "k_frame64")),
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn("r03_f", "k_cand64p"), 32768),
+        "k_autocorr": floor("k_autocorr4<13,4,true,true>", pick_loops(ac), cost, dyn("r03_f", "k_autocorr4")),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn("r03_f", "k_frame64")),
     }
     # config 2: no LPC (SELF variant)
     c2 = blocks_of(A("cand_direct.gfx950.s"), "k_cand64pILi64ELi16ELb1ELb1ELb1")
