@@ -1659,7 +1659,7 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t 
         launch_autocorr_mfma(p, (uint32_t)((nc + 3) / 4), p.block_size, c->d_window_full, c->d_ac, st);
         if (it == 1) (void)hipEventRecord(c->ev[1], st);
     }
-    launch_lpc_generic(p, (uint32_t)((nc + 63) / 64), st);
+    launch_lpc(p, c->knobs, (uint32_t)((nc + 63) / 64), st);   // the product's own K4 (no scratch, unlike the generic k_lpc)
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);

@@ -159,7 +159,6 @@ Knobs read_knobs();   // flacenc_gpu.hip
 namespace flacgpu_k {
 // lpc.hip
 void launch_lpc(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t st);
-void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st);
 // cand.hip
 // returns true when the kernel also chose the channel assignment and wrote out_plan / frame_plan (the
 // persistent stereo kernels: K6 in the workgroup) -- no k_decide launch for those frames then

@@ -18,7 +18,4 @@ void launch_lpc(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t s
     else if (kn.lpc_dyn) hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lpc_u<32>), dim3(blocks), dim3(64), 0, st, p);
 }
-void launch_lpc_generic(const Params &p, uint32_t blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(64), 0, st, p);
-}
 }  // namespace flacgpu_k
