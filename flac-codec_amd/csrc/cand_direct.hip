@@ -26,6 +26,6 @@ bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<64, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);
         return true;
     }
-    return false;
+    return launch_cand64_direct_short(p, kn, B, blocks, st);   // cand_direct_b.hip
 }
 }  // namespace flacgpu_k

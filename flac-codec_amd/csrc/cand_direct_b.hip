@@ -1,0 +1,44 @@
+// cand_direct_b.hip -- the DIRECT-input instantiations of the persistent candidate kernel k_cand64p for the shorter
+// wave block lengths (1024 / 1152 / 2048 / 2304 samples: Options::fast() and friends, encode.rs:1635-1644), with LPC
+// (order <= 16) and without (SELF).  A translation unit of its own only to compile beside cand_direct.hip.
+#include "kernels/types.h"
+
+#include <stdlib.h>
+
+namespace {
+#include "kernels/common.inc"
+#include "kernels/wave_cand.inc"
+
+// resident workgroups per CU of one instantiation (registers and LDS image differ per block length), asked once
+template <int SPL, bool SELF>
+uint32_t resident_per_cu() {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cand64p<SPL, 16, true, true, SELF>, WG, 0) != hipSuccess || n < 1)
+            n = 3;
+        per_cu = n > 8 ? 8 : n;
+    }
+    return (uint32_t)per_cu;
+}
+template <int SPL>
+void launch_spl(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t st) {
+    const bool lpc = p.max_lpc_order > 0;
+    const uint32_t cap = kn.cand_grid ? kn.cand_grid : 256u * (lpc ? resident_per_cu<SPL, false>() : resident_per_cu<SPL, true>());
+    const uint32_t grid = blocks < cap ? blocks : cap;
+    if (!lpc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);
+}
+}  // namespace
+
+namespace flacgpu_k {
+bool launch_cand64_direct_short(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st) {
+    switch (B) {
+    case 2304: launch_spl<36>(p, kn, blocks, st); return true;
+    case 2048: launch_spl<32>(p, kn, blocks, st); return true;
+    case 1152: launch_spl<18>(p, kn, blocks, st); return true;
+    case 1024: launch_spl<16>(p, kn, blocks, st); return true;
+    default: return false;
+    }
+}
+}  // namespace flacgpu_k

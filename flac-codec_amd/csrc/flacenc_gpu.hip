@@ -63,6 +63,7 @@ Knobs read_knobs() {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
     k.no_direct = on("FLACGPU_NO_DIRECT");
+    k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
     k.no_w64 = on("FLACGPU_NO_W64");
     k.no_persist = on("FLACGPU_NO_PERSIST");
@@ -583,16 +584,18 @@ static int resolve_stream(flacgpu_ctx *c, void *stream, hipStream_t *out) {
 
 // packed_bytes != 0: the PCM sits in c->d_in as interleaved little-endian samples of that many bytes
 // Whether a batch of interleaved i32 PCM can be analysed and assembled in place (Params::inter): stereo with
-// the four L/R/M/S candidates of <= 24-bit samples, whole 4096-sample blocks (the shorter wave block lengths were
-// tried: their non-persistent candidate kernel reads the interleaved frame four times, 0.114 -> 0.172 ms for
-// 1152-sample blocks, more than the split pass costs), and every stage on its wave kernel -- none of the knobs
-// that select an older or generic kernel (they read Params::planar).
+// the four L/R/M/S candidates of <= 24-bit samples, whole blocks of one of the wave block lengths (4096; 1024 / 1152 /
+// 2048 / 2304 with LPC order <= 16 -- the persistent candidate kernel stages the interleaved frame once per frame in
+// LDS; the non-persistent one read it once per candidate wave and lost to the split pass, 0.114 -> 0.172 ms at 1152
+// samples), and every stage on its wave kernel -- none of the knobs that select an older or generic kernel (they read
+// Params::planar).
 static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
     const Knobs &kn = c->knobs;
     const bool off = kn.no_direct || kn.no_fast || kn.no_w64 || kn.no_persist || kn.no_ac3 || kn.ac_private ||
                      kn.experiment_mfma_ac || kn.no_fused_pack || kn.no_frame64;
     const uint32_t B = p.block_size;
-    return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && B == FN && last_len == B &&
+    const bool block_ok = B == FN || (wave_block_size(B) && p.max_lpc_order <= 16 && !kn.no_direct_short);
+    return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && block_ok && last_len == B &&
            p.max_po <= 6 && p.ac_split != 2 &&
            (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
 }
@@ -710,7 +713,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     if (!have_orbits)
         launch_orbits(p, c->d_orbits, st);
     const size_t dyn2 = (2 * (size_t)B + B / 16 + 16) * sizeof(int32_t);
-    if (c->stereo4 && !p.exhaustive && !c->abs_valid) {   // (K0 summed the magnitudes on the way otherwise)
+    // (K0 summed the magnitudes on the way otherwise; direct input without LPC: k_cand64p<..., SELF> makes the choice)
+    if (c->stereo4 && !p.exhaustive && !c->abs_valid && !(direct && p.max_lpc_order == 0)) {
         begin(1);
         if (direct) hipLaunchKernelGGL(k_stereo_stats_t<true>, dim3(n_frames), dim3(WG), 0, st, p);
         else hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(n_frames), dim3(WG), 0, st, p);

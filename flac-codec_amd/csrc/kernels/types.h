@@ -146,7 +146,8 @@ struct Knobs {
          no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false,
          ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
-         early_download = false;   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
+         early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
+         no_direct_short = false;  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;
@@ -165,6 +166,7 @@ void launch_lpc(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t s
 bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_direct.hip
 bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
+bool launch_cand64_direct_short(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);
 // cand_split.hip: eight waves per stereo frame ({L, R, mid, side} x {FIXED, LPC}); false: shape not served
 bool launch_cand64_split(const Params &p, uint32_t B, uint32_t frames, uint32_t grid_cap, hipStream_t st);
 // autocorr.hip

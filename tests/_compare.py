@@ -81,3 +81,22 @@ def planar_frames(interleaved, channels, block_size):
     for s in range(0, total, block_size):
         out.append(np.ascontiguousarray(pcm[s:s + block_size].T))
     return out
+
+
+def frames_the_reference_cannot_decode(subs, n_frames, channels, block_size, last_len):
+    """Frames holding a subframe whose residual chunks do not tile the block.  best_partitions (encode.rs:3865-3896)
+    tries every partition count up to 2^min(tz(n), max) and cuts the residuals with rchunks(n / count); when n / count
+    is smaller than the predictor order the chunks are FEWER than `count`, and if their number happens to be a power
+    of two the candidate survives the filter of :3881 and is written with partition order log2(chunks) (:3903) -- a
+    partition length that is not n >> order.  The reference's own decoder (decode.rs:1812-1820: rchunks_mut(n / 2^order),
+    `partitions.len() != partition_count` -> InvalidPartitionOrder) rejects such a frame.  It takes a frame of fewer
+    than 2 x order samples (a very short last frame); the encoder here reproduces the reference's bytes, and the device
+    decoder, like the reference's, flags the frame.  Returns the set of such frame indices."""
+    bad = set()
+    for f in range(n_frames):
+        n = block_size if f + 1 < n_frames else last_len
+        for ch in range(channels):
+            s = subs[f * channels + ch]
+            if s.type in (2, 3) and (s.part_len << s.partition_order) != n:
+                bad.add(f)
+    return bad

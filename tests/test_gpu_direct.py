@@ -1,4 +1,4 @@
-"""DIRECT input (Params::inter): interleaved i32 stereo PCM of whole 4096-sample blocks is analysed and
+"""DIRECT input (Params::inter): interleaved i32 stereo PCM of whole blocks of a wave block length is analysed and
 assembled in place -- no K0 split, the wasted-bits ORs come out of the autocorrelation kernel, whose sums
 are scaled by 2^(-2 wasted) instead of being formed from shifted samples (kernels/autocorr.inc).  Every case
 must give the oracle's bytes, the bytes of the K0 path (FLACGPU_NO_DIRECT), and survive the consumers that
@@ -119,6 +119,50 @@ def test_fast_channel_choice(monkeypatch):
     x[8192:12288, 1] = x[8192:12288, 0]
     check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False)
     check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=12, exhaustive=False)
+
+
+@pytest.mark.parametrize("blk", [1024, 1152, 2048, 2304])
+def test_shorter_wave_block_lengths(monkeypatch, blk):
+    """1024 / 1152 / 2048 / 2304-sample blocks (Options::fast(), encode.rs:1635-1644): the persistent candidate kernel
+    stages the interleaved frame in LDS as segments of whole consumer lanes (7 lanes = 63 pieces per segment at 1152
+    samples, the last segment a single lane clamped inside the frame), k_frame64 reads 9 / 18 pieces per lane.  A small
+    grid makes every workgroup walk several frames (the prefetch of the next frame behind the current one)."""
+    monkeypatch.setenv("FLACGPU_CAND_GRID", "3")
+    check(synth_fast(980 + blk, 2, 24, blk * 11), 24, monkeypatch, B=blk)
+    check(synth_fast(981 + blk, 2, 16, blk * 7), 16, monkeypatch, max_lpc=8, rate=44100, B=blk, max_po=4)
+    # Options::fast(): no LPC, no mid-side, channel choice by abs sums
+    check(synth_fast(982 + blk, 2, 16, blk * 9), 16, monkeypatch, max_lpc=0, exhaustive=False, mid_side=False, B=blk)
+    check(synth_fast(983 + blk, 2, 24, blk * 6), 24, monkeypatch, max_lpc=12, exhaustive=False, B=blk)
+    x = synth_fast(984 + blk, 2, 16, blk * 8).reshape(-1, 2).astype(np.int64)
+    x[:, 0] <<= 4
+    x[:, 1] <<= 2                                                  # wasted bits: L 4, R 2, mid 1 (or more), side 2
+    x[blk:2 * blk] = 0                                             # a silent frame
+    x[2 * blk:3 * blk, 1] = 0                                      # R all zero
+    x[3 * blk:4 * blk, 0] = x[3 * blk:4 * blk, 1]                  # side all zero
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, B=blk)
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, B=blk)
+    monkeypatch.delenv("FLACGPU_CAND_GRID")
+    rng = np.random.Generator(np.random.PCG64(985 + blk))
+    check(rng.integers(-(1 << 23), 1 << 23, size=blk * 2 * 5, dtype=np.int64).astype(np.int32), 24, monkeypatch, B=blk)
+
+
+def test_shorter_blocks_knob_and_last_short_frame(monkeypatch):
+    """FLACGPU_NO_DIRECT_SHORT keeps the shorter block lengths on the split path (A/B runs); a batch that ends in a
+    short frame is not eligible for direct input at any block length."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    blk = 1152
+    pcm = synth_fast(990, 2, 16, blk * 6)
+    for env, want_split in ((None, False), ("1", True)):
+        if env:
+            monkeypatch.setenv("FLACGPU_NO_DIRECT_SHORT", env)
+        an = GpuAnalyzer(blk, 6, 0, False, False, 2, 0.5, 16, 2, max_frames=6)
+        an.set_timing(True)
+        an.analyze(pcm, 6, blk)
+        assert ("k_deinterleave" in an.kernel_ms()) == want_split
+        an.analyze(pcm[: 2 * (blk * 5 + 100)], 6, 100)
+        assert "k_deinterleave" in an.kernel_ms()
+        an.close()
 
 
 def test_device_buffer_input(monkeypatch):

@@ -147,3 +147,28 @@ def test_fork_join_task_structure_gives_the_same_bytes():
         for th in (-2, -4, -9):
             rc, out, _ = orc.encode_stream(orc.options(preset), 44100, bps, ch, pcm, total_known=True, threads=th)
             assert rc == 0 and out == ref
+
+
+def test_partition_corner_of_very_short_frames():
+    """A frame of fewer than 2 x order samples can leave best_partitions (encode.rs:3865-3896) in a shape the
+    reference's own decoder rejects: for 4 samples and FIXED order 2 the candidate "4 partitions" cuts the 2 residuals
+    with rchunks(4 / 4) into TWO chunks of one -- a power of two, so it passes the filter of :3881 -- and, when its
+    estimate is the smallest, is written as partition order log2(2) = 1 (:3903) with partitions of ONE residual each,
+    where the format (and decode.rs:1812-1820: rchunks_mut(4 / 2) gives one chunk, `partitions.len() != 2` ->
+    InvalidPartitionOrder) has partition 0 empty and partition 1 holding both.  The restatement keeps the
+    reference's behaviour (the GPU path reproduces these bytes: tests/test_gpu_random_configs.py); its decoder, like
+    the reference's, does not accept the stream."""
+    left = np.array([-197, -412, -452, -473], dtype=np.int32)
+    right = np.array([-60, -323, -396, -450], dtype=np.int32)
+    opts = orc.options("best", block_size=4608, max_partition_order=3, max_lpc_order=32, mid_side=0, exhaustive=1,
+                       window_kind=1, window_param=0.0)
+    rc, frame, plan = orc.encode_frame(opts, 8000, 16, np.stack([left, right]), frame_number=130)
+    assert rc == 0
+    assert frame.hex() == "fff86488c282035802ff3bfe64fe3cfe2714ffbbffe9c1477c00804d"
+    side = plan.sub[1]
+    assert (side.type, side.order, side.bps, side.partition_order, side.n_partitions) == (2, 2, 17, 1, 2)
+    assert list(side.part_len[:2]) == [1, 1] and list(side.rice[:2]) == [4, 255] and side.bits == 67
+    rc, data, _ = orc.encode_stream(opts, 8000, 16, 2, np.stack([left, right], axis=1).reshape(-1))
+    assert rc == 0
+    rc2, _, _ = orc.decode_stream(data)
+    assert rc2 != 0

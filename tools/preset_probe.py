@@ -3,7 +3,11 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
 from _pcm import synth_fast
 from flac_codec_amd.gpu import GpuAnalyzer
-for name, B, po, lpc, ms, ex in (("fast", 1152, 3, 0, False, False), ("default", 4096, 5, 8, True, True), ("best", 4096, 6, 12, True, True)):
+CASES = (("fast", 1152, 3, 0, False, False), ("default", 4096, 5, 8, True, True), ("best", 4096, 6, 12, True, True),
+         # the other wave block lengths at the `best` settings (direct input since r03; FLACGPU_NO_DIRECT_SHORT=1 for A/B)
+         ("best-1024", 1024, 6, 12, True, True), ("best-1152", 1152, 6, 12, True, True),
+         ("best-2048", 2048, 6, 12, True, True), ("best-2304", 2304, 6, 12, True, True))
+for name, B, po, lpc, ms, ex in [c for c in CASES if len(sys.argv) < 2 or c[0] in sys.argv[1:]]:
     F = 8192 * 4096 // B
     base = synth_fast(77, 2, 16, B * 512)
     pcm = np.tile(base, (F + 511) // 512)[: F * B * 2]
