@@ -290,10 +290,24 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         t = time.perf_counter()
         an.encode_frames(batch, 1024, BLOCK, 0, rate)
         times.append(time.perf_counter() - t)
+    ref_bytes, ref_off = an.encode_frames(batch, 1024, BLOCK, 0, rate)
+    pin_bytes, pin_off, pin_times = an.encode_frames_pinned(batch, 1024, BLOCK, 0, rate, repeat=6)
+    assert pin_bytes == ref_bytes and pin_off == ref_off
     an.close()
     out["encode_frames_pcie_inclusive"] = {
         "Msamples/s": round(batch.size / statistics.median(times) / 1e6, 1), "frames": 1024,
-        "note": "flacgpu_encode_frames, one context, synchronous: H2D + kernels + D2H"}
+        "pinned_host_buffers_Msamples/s": round(batch.size / statistics.median(pin_times[1:]) / 1e6, 1),
+        "note": "flacgpu_encode_frames, one context, synchronous: H2D + kernels + D2H; first figure from pageable "
+                "numpy arrays (a fresh output array per call), second one with both host buffers from "
+                "flacgpu_host_alloc (the copies at the link's rate)"}
+    # the headline batch through the same call: 8192 frames, pinned buffers (268 MB in, the frames out)
+    big = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=FRAMES, device=device)
+    whole = pcm[: FRAMES * BLOCK * C]
+    if whole.size == FRAMES * BLOCK * C:
+        _, _, big_times = big.encode_frames_pinned(whole, FRAMES, BLOCK, 0, rate, repeat=4)
+        out["encode_frames_pcie_inclusive"]["pinned_8192_frames_Msamples/s"] = round(
+            whole.size / statistics.median(big_times[1:]) / 1e6, 1)
+    big.close()
     return out
 
 

@@ -219,3 +219,17 @@ def test_more_than_8192_frames_in_one_batch():
     res, _ = an.verify_device(44100, 3)
     assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n_frames, 0, 0, 0)
     an.close()
+
+
+def test_pinned_host_buffers_give_the_same_frames():
+    """flacgpu_encode_frames with both host buffers from flacgpu_host_alloc (the PCIe-inclusive figure of the bench):
+    same bytes and offsets as from pageable arrays, call after call, with a short last frame."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    B = 4096
+    pcm = synth_fast(4242, 2, 24, B * 6 + 1000)
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=7)
+    want, want_off = an.encode_frames(pcm, 7, 1000, 9, 48000)
+    got, off, times = an.encode_frames_pinned(pcm, 7, 1000, 9, 48000, repeat=3)
+    an.close()
+    assert got == want and off == want_off and len(times) == 3
