@@ -62,6 +62,45 @@ def test_full_size_roundtrip(ch, bps, rate, frames, lpc):
         assert rc == 0 and fb in data, f"frame {f} not byte-identical to the oracle"
 
 
+@pytest.mark.parametrize("block,bps,lpc,exhaustive,mid_side", [
+    (1152, 16, 0, False, False),    # Options::fast() at the bench's size: 29 127 frames per batch
+    (1152, 24, 12, True, True),
+    (2304, 24, 12, True, True),
+    (1024, 16, 8, False, True),
+    (2048, 24, 12, True, False),
+])
+def test_full_size_short_blocks_read_in_place(block, bps, lpc, exhaustive, mid_side):
+    """The shorter wave block lengths at the bench's batch size (67 M samples of interleaved stereo resident in HBM,
+    analysed and assembled in place): every frame decodes back to its input on the device (structure, CRC-16, PCM),
+    frames sampled over the batch equal the oracle's, and the copy-input path gives the same bytes."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    frames = 8192 * 4096 // block
+    pcm = tiled(500 + block + bps + lpc, 2, bps, frames, block=block, distinct=509)
+    d = torch.from_numpy(pcm).cuda()
+    an = GpuAnalyzer(block, 6, lpc, mid_side, exhaustive, 2, 0.5, bps, 2, max_frames=frames)
+    an.set_timing(True)
+    an.analyze_device(d.data_ptr(), frames, block)
+    assert "k_deinterleave" not in an.kernel_ms()
+    an.set_timing(False)
+    an.encode_device(d.data_ptr(), frames, block, 3, 44100)
+    data, off = an.fetch_frames(frames)
+    res, _ = an.verify_device(44100, 3)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs, res.samples_differ) == (frames, 0, 0, 0, 0)
+    an.set_tuning(an.TUNE_COPY_INPUT, 1)
+    an.encode_device(d.data_ptr(), frames, block, 3, 44100)
+    data2, off2 = an.fetch_frames(frames)
+    an.close()
+    assert off2 == off and data2 == data
+    oo = orc_options_for(block, 6, lpc, mid_side, exhaustive)
+    for f in (0, 1, 508, 509, frames // 2, frames - 2, frames - 1):
+        blk = pcm[f * block * 2:(f + 1) * block * 2].reshape(block, 2).T
+        rc, fb, _ = orc.encode_frame(oo, 44100, bps, np.ascontiguousarray(blk), frame_number=3 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
+
+
 def test_batch_size_independence():
     """The same stream encoded with different GPU batch sizes gives identical bytes."""
     from flac_codec_amd.encode import FlacSampleWriter, Options
