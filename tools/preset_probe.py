@@ -12,14 +12,15 @@ for name, B, po, lpc, ms, ex in [c for c in CASES if len(sys.argv) < 2 or c[0] i
     base = synth_fast(77, 2, 16, B * 512)
     pcm = np.tile(base, (F + 511) // 512)[: F * B * 2]
     d = torch.from_numpy(pcm).cuda()
-    ans = [GpuAnalyzer(B, po, lpc, ms, ex, 2, 0.5, 16, 2, max_frames=F) for _ in range(4)]
+    NCTX = int(__import__('os').environ.get('PROBE_CONTEXTS', '4'))
+    ans = [GpuAnalyzer(B, po, lpc, ms, ex, 2, 0.5, 16, 2, max_frames=F) for _ in range(NCTX)]
     ss = [torch.cuda.Stream() for _ in ans]
     for i in range(16):
-        ans[i % 4].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % 4].cuda_stream)
+        ans[i % NCTX].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % NCTX].cuda_stream)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for i in range(100):
-        ans[i % 4].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % 4].cuda_stream)
+        ans[i % NCTX].encode_device(d.data_ptr(), F, B, 0, 44100, stream=ss[i % NCTX].cuda_stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 100
     ans[0].set_timing(True)
