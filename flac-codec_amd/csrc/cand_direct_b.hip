@@ -10,23 +10,30 @@ namespace {
 #include "kernels/wave_cand.inc"
 
 // resident workgroups per CU of one instantiation (registers and LDS image differ per block length), asked once
-template <int SPL, bool SELF>
+template <int SPL, bool SELF, bool PAIR>
 uint32_t resident_per_cu() {
     static int per_cu = 0;
     if (!per_cu) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cand64p<SPL, 16, true, true, SELF>, WG, 0) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cand64p<SPL, 16, true, true, SELF, PAIR>, PAIR ? 128 : WG, 0) !=
+                hipSuccess || n < 1)
             n = 3;
-        per_cu = n > 8 ? 8 : n;
+        per_cu = n > 16 ? 16 : n;
     }
     return (uint32_t)per_cu;
 }
 template <int SPL>
 void launch_spl(const Params &p, const Knobs &kn, uint32_t blocks, hipStream_t st) {
     const bool lpc = p.max_lpc_order > 0;
-    const uint32_t cap = kn.cand_grid ? kn.cand_grid : 256u * (lpc ? resident_per_cu<SPL, false>() : resident_per_cu<SPL, true>());
-    const uint32_t grid = blocks < cap ? blocks : cap;
-    if (!lpc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
+    // without LPC and with the fast channel choice only two subframes per frame are analysed: two waves per frame
+    const bool pair = !lpc && !p.exhaustive && !kn.no_cand_pair;
+    const uint32_t per_cu = pair ? resident_per_cu<SPL, true, true>() : lpc ? resident_per_cu<SPL, false, false>()
+                                                                          : resident_per_cu<SPL, true, false>();
+    const uint32_t cap = kn.cand_grid ? kn.cand_grid : 256u * per_cu;
+    const uint32_t units = pair ? p.fcount : blocks;   // workgroup turns: frames
+    const uint32_t grid = units < cap ? units : cap;
+    if (pair) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true, true, true>), dim3(grid), dim3(128), 0, st, p);
+    else if (!lpc) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true, true>), dim3(grid), dim3(WG), 0, st, p);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64p<SPL, 16, true, true>), dim3(grid), dim3(WG), 0, st, p);
 }
 }  // namespace

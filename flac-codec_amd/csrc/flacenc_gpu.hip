@@ -63,6 +63,7 @@ Knobs read_knobs() {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
     k.no_direct = on("FLACGPU_NO_DIRECT");
+    k.no_cand_pair = on("FLACGPU_NO_CAND_PAIR");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
     k.no_w64 = on("FLACGPU_NO_W64");

@@ -147,7 +147,8 @@ struct Knobs {
          ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
-         no_direct_short = false;  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
+         no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
+         no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;

@@ -141,6 +141,17 @@ def test_shorter_wave_block_lengths(monkeypatch, blk):
     x[3 * blk:4 * blk, 0] = x[3 * blk:4 * blk, 1]                  # side all zero
     check(x.astype(np.int32).reshape(-1), 24, monkeypatch, B=blk)
     check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, B=blk)
+    # fast channel choice without LPC: two waves per frame (k_cand64p<..., PAIR>), every assignment in reach
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False, mid_side=True, B=blk)
+    check(x.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False, mid_side=False, B=blk)
+    y = synth_fast(986 + blk, 2, 16, blk * 10).reshape(-1, 2).astype(np.int64)
+    y[2 * blk:4 * blk, 1] = y[2 * blk:4 * blk, 0] + (y[2 * blk:4 * blk, 1] >> 6)    # R ~ L: left-side / mid-side frames
+    y[5 * blk:7 * blk, 0] = -y[5 * blk:7 * blk, 1]                                  # L = -R: mid ~ 0
+    check(y.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False, mid_side=True, B=blk)
+    check(y.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False, mid_side=False, B=blk, max_po=3)
+    monkeypatch.setenv("FLACGPU_NO_CAND_PAIR", "1")   # the four-wave kernel on the same input
+    check(y.astype(np.int32).reshape(-1), 24, monkeypatch, max_lpc=0, exhaustive=False, mid_side=True, B=blk)
+    monkeypatch.delenv("FLACGPU_NO_CAND_PAIR")
     monkeypatch.delenv("FLACGPU_CAND_GRID")
     rng = np.random.Generator(np.random.PCG64(985 + blk))
     check(rng.integers(-(1 << 23), 1 << 23, size=blk * 2 * 5, dtype=np.int64).astype(np.int32), 24, monkeypatch, B=blk)
