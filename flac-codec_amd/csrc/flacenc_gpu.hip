@@ -142,6 +142,8 @@ struct flacgpu_ctx {
     int lag_split = 4;               // FLACGPU_TUNE_LAG_SPLIT
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
+    unsigned long long *d_tile_sync = nullptr;   // k_layout's tile exchange (PackParams::tile_sync)
+    uint32_t layout_epoch = 0;
     uint64_t packed_cap = 0;        // bytes
     bool packed_valid = false;
     bool resid_valid = false;       // d_resid holds the rows of the last analysed batch
@@ -460,6 +462,8 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
     ALLOC(c->d_frame_off, F + 1);
+    ALLOC(c->d_tile_sync, F / 1024 + 2);
+    HIP_TRY(hipMemset(c->d_tile_sync, 0, sizeof(unsigned long long) * (F / 1024 + 2)));
     if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
     ALLOC(c->d_ties, F * NC);
     if (c->stereo4 && !o->exhaustive_channel_correlation) ALLOC(c->d_abs, F * 4);
@@ -507,7 +511,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
-    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off);
+    (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_tile_sync);
     (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify); (void)hipFree(c->d_big);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -599,6 +603,19 @@ static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last
     return !off && c->stereo4 && c->channels == 2 && c->bps <= 24 && block_ok && last_len == B &&
            p.max_po <= 6 && p.ac_split != 2 &&
            (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
+}
+
+// k_layout's tiles find each other through PackParams::tile_sync, whose words carry the launch's 24-bit epoch: a new
+// one per launch, the words wiped (in stream order) when the counter wraps
+static int next_layout_epoch(flacgpu_ctx *c, PackParams &q, hipStream_t st) {
+    c->layout_epoch = (c->layout_epoch + 1) & 0xFFFFFFu;
+    if (c->layout_epoch == 0) {
+        HIP_TRY(hipMemsetAsync(c->d_tile_sync, 0, sizeof(unsigned long long) * (c->max_frames / 1024 + 2), st));
+        c->layout_epoch = 1;
+    }
+    q.tile_sync = c->d_tile_sync;
+    q.epoch = c->layout_epoch;
+    return FLACGPU_OK;
 }
 
 // d_planar of the last batch, for the consumers outside the hot path (verification against the input,
@@ -963,6 +980,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     q.cap_bytes = c->packed_cap;
     hipEvent_t *ev = c->ev;  // reuse the event pool: [0..3]
     if (c->timing) (void)hipEventRecord(ev[0], st);
+    if (int rc = next_layout_epoch(c, q, st)) return rc;
     launch_layout(p, q, st);
     if (after_layout) HIP_TRY(hipEventRecord(after_layout, st));
     // frames of a wave block length are assembled whole in LDS by k_frame64 (residuals recomputed
@@ -1117,6 +1135,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         if (!launch_cand64(r, c->knobs, B, (ncb + 3) / 4, st)) hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's
         if (half) HIP_TRY(hipStreamWaitEvent(st, c->ev_layout, 0));
+        if (int rc = next_layout_epoch(c, q, st)) return rc;
         launch_layout(r, q, st);
         if (!half) HIP_TRY(hipEventRecord(c->ev_layout, st));
         launch_frame64(r, q, B, r.fcount, l64, st);

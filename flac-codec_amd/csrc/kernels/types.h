@@ -110,6 +110,10 @@ struct PackParams {
     uint32_t *out_words;      // packed bytes, viewed as big-endian-filled 32-bit words
     uint64_t *frame_off;      // [n_frames + 1] byte offsets
     uint64_t cap_bytes;
+    // k_layout's tile exchange: one word per 1024-frame tile, (epoch << 40) | bytes of the tile; the epoch is new for
+    // every launch, so the words are never reset
+    unsigned long long *tile_sync = nullptr;
+    uint32_t epoch = 0;
 };
 
 // words reserved for a subframe's bit string: a chosen subframe is never longer than its

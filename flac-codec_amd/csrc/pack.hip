@@ -24,7 +24,7 @@ void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t f
     else launch_frame64_short(p, q, B, frames, lds, st);                   // <= 4 channels
 }
 void launch_layout(const Params &p, const PackParams &q, hipStream_t st) {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, p, q);
+    hipLaunchKernelGGL(k_layout, dim3((p.fcount + 1023) / 1024), dim3(1024), 0, st, p, q);
 }
 void launch_zero(const PackParams &q, uint32_t n_frames, hipStream_t st) {
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, n_frames);
