@@ -262,7 +262,7 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     usable = int(out["host"]["usable_cpus"])
     # one writer thread per stream: they sleep while the GPU and the shared MD5 engines work (blocking waits),
     # so more threads than usable CPUs cost nothing and keep 64 MD5 chains in flight
-    n_threads = n_streams
+    n_threads = min(n_streams, 32)   # (the front end opens all streams at once whatever the thread count; 64 threads on a 16-CPU quota meet the throttle)
     be = BatchEncoder(opts(), threads=n_threads)
     views = be.encode(streams, rate, bps, C, copy=False)      # warm-up: lanes, pinned staging, output buffers
     rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, per, total_known=True)

@@ -1301,33 +1301,72 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
         if (shared.batch_frames == 0) shared.batch_frames = 512;
     }
     const flacenc_options *opts = &shared;
-    std::atomic<size_t> next{0};
+    // Two phases per stream, claimed separately: SUBMIT (writer, staging, MD5 pieces queued, GPU batches queued) and
+    // FINISH (wait for the hash and the frames, metadata).  A worker submits as long as fewer than kOpen streams are
+    // open and finishes the oldest open one otherwise -- so the streams' MD5 chains (26 ms for 512 frames of 24-bit
+    // stereo: the burst's floor) all start within the few milliseconds the staging takes, whatever the thread count
+    // (one stream per worker from start to end had 16 workers take 64 streams in four rounds of 28 ms; 64 workers
+    // on a 16-CPU quota burn twice the CPU time and meet the throttle).  kOpen = the shared MD5 engines' lanes.
+    constexpr size_t kOpen = 64;
+    std::mutex claim_mu;
+    size_t next = 0, next_fin = 0;
+    std::vector<std::unique_ptr<flacenc_writer>> open_writers(n_jobs);
+    std::unique_ptr<std::atomic<int>[]> submitted(new std::atomic<int>[n_jobs ? n_jobs : 1]);
+    std::vector<double> t_start(n_jobs, 0.0);
+    for (size_t i = 0; i < n_jobs; i++) submitted[i].store(0, std::memory_order_relaxed);
     const double t_begin = now_ms();
+    auto submit = [&](size_t i) {
+        flacenc_job &j = jobs[i];
+        j.out_len = 0;
+        t_start[i] = now_ms();
+        if (!j.samples || !j.out || j.bits_per_sample < 1 || j.bits_per_sample > 32 || j.channels == 0 ||
+            j.count % j.channels || j.count == 0) {
+            j.status = FLACENC_ERR_INVALID_ARG;
+            return;
+        }
+        std::unique_ptr<flacenc_writer> w(new flacenc_writer());
+        w->kind = flacenc_writer::SAMPLE;
+        w->use_fixed_sink(j.out, j.out_cap);
+        int rc = w->init(*opts, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
+        if (!rc) rc = w->write_direct(j.samples, j.count);
+        j.status = rc;
+        j.start_ms = t_start[i] - t_begin;
+        if (!rc) open_writers[i] = std::move(w);
+    };
+    auto finish = [&](size_t i) {
+        while (submitted[i].load(std::memory_order_acquire) == 0) std::this_thread::yield();   // (its submitter is at work)
+        std::unique_ptr<flacenc_writer> w = std::move(open_writers[i]);
+        if (!w) return;   // rejected or failed in its first phase: status says so
+        flacenc_job &j = jobs[i];
+        j.status = w->finalize();
+        j.out_len = w->sink.fixed_len;
+        j.elapsed_ms = now_ms() - t_start[i];
+        j.pack_ms = w->stats.pack_ms;
+        j.gpu_ms = w->stats.gpu_ms;
+        j.md5_ms = w->stats.md5_ms;
+    };
     auto work = [&]() {
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= n_jobs) return;
-            flacenc_job &j = jobs[i];
-            j.out_len = 0;
-            if (!j.samples || !j.out || j.bits_per_sample < 1 || j.bits_per_sample > 32 || j.channels == 0 ||
-                j.count % j.channels || j.count == 0) {
-                j.status = FLACENC_ERR_INVALID_ARG;
-                continue;
+            size_t idx;
+            bool do_submit;
+            {
+                std::lock_guard<std::mutex> lock(claim_mu);
+                if (next < n_jobs && next - next_fin < kOpen) {
+                    do_submit = true;
+                    idx = next++;
+                } else if (next_fin < next) {
+                    do_submit = false;
+                    idx = next_fin++;
+                } else {
+                    return;   // everything claimed
+                }
             }
-            const double t0 = now_ms();
-            std::unique_ptr<flacenc_writer> w(new flacenc_writer());
-            w->kind = flacenc_writer::SAMPLE;
-            w->use_fixed_sink(j.out, j.out_cap);
-            int rc = w->init(*opts, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
-            if (!rc) rc = w->write_direct(j.samples, j.count);
-            if (!rc) rc = w->finalize();
-            j.status = rc;
-            j.out_len = w->sink.fixed_len;
-            j.start_ms = t0 - t_begin;
-            j.elapsed_ms = now_ms() - t0;
-            j.pack_ms = w->stats.pack_ms;
-            j.gpu_ms = w->stats.gpu_ms;
-            j.md5_ms = w->stats.md5_ms;
+            if (do_submit) {
+                submit(idx);
+                submitted[idx].store(1, std::memory_order_release);
+            } else {
+                finish(idx);
+            }
         }
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
