@@ -277,8 +277,8 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                            "frames_per_stream": 512, "host_cores": os.cpu_count(), "host_threads": n_threads,
                            "byte_identical_to_oracle": True,
                            "best_Msamples/s": round(n_streams * per.size / min(times) / 1e6, 1),
-                           "note": "median of 5 calls of flacenc_encode_many (C++ front end: one writer per "
-                                   "worker thread, pooled lanes, the streams' MD5 chains on the shared 16-lane "
+                           "note": "median of 5 calls of flacenc_encode_many (C++ front end: all streams open at "
+                                   "once, submit and finish phases claimed by the worker threads, pooled lanes, the streams' MD5 chains on the shared 16-lane "
                                    "AVX-512 engines, waits that sleep, frames written by k_frame64 straight into pinned host memory); host PCM "
                                    "-> .flac bytes in caller buffers"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
