@@ -107,6 +107,25 @@ def test_batch_front_end_matches_oracle():
             assert rc == 0 and o == ref
 
 
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_batch_front_end_more_streams_than_open_slots(threads):
+    """flacenc_encode_many keeps at most 64 streams open (submit and finish phases are claimed separately by its
+    workers): 70 short streams with one, two and five threads -- the last streams are submitted only after the first
+    ones were finished --, every one the oracle's."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    streams = [synth_fast(1400 + i, 2, 16, 1152 * (1 + i % 4) + 11 * i) for i in range(70)]
+    streams = [s[: s.size - s.size % 2] for s in streams]
+    be = BatchEncoder(Options.fast().batch_frames(4), threads=threads)
+    outs = be.encode(streams, 44100, 16, 2)
+    assert len(outs) == 70
+    for i in (0, 1, 33, 63, 64, 65, 69):
+        rc, ref, _ = orc.encode_stream(orc.options("fast"), 44100, 16, 2, streams[i], total_known=True)
+        assert rc == 0 and outs[i] == ref, i
+    refs = {i: orc.encode_stream(orc.options("fast"), 44100, 16, 2, streams[i], total_known=True)[1] for i in range(70)}
+    assert all(outs[i] == refs[i] for i in range(70))
+
+
 def test_many_writers_on_the_shared_md5_engines():
     """More concurrent streams than one engine has lanes, 24-bit (3-byte samples: runs that are no multiple of
     the 64-byte MD5 block), ragged lengths, sleeping waits: every finished stream -- STREAMINFO MD5 included --
