@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $ROOT/tools/e2e_probe.py 64,64,0,2 > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python3 $ROOT/tools/e2e_probe.py ${PROBE_CASE:-64,32,0,2} > $OUT/trace.log 2>&1
 cd $ROOT
 tail -2 $OUT/trace.log | cut -c1-160
 python3 - $OUT <<'PY'
