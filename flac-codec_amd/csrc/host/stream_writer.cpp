@@ -1301,21 +1301,25 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
         if (shared.batch_frames == 0) shared.batch_frames = 512;
     }
     const flacenc_options *opts = &shared;
-    // Two phases per stream, claimed separately: SUBMIT (writer, staging, MD5 pieces queued, GPU batches queued) and
-    // FINISH (wait for the hash and the frames, metadata).  A worker submits as long as fewer than kOpen streams are
-    // open and finishes the oldest open one otherwise -- so the streams' MD5 chains (26 ms for 512 frames of 24-bit
-    // stereo: the burst's floor) all start within the few milliseconds the staging takes, whatever the thread count
-    // (one stream per worker from start to end had 16 workers take 64 streams in four rounds of 28 ms; 64 workers
-    // on a 16-CPU quota burn twice the CPU time and meet the throttle).  kOpen = the shared MD5 engines' lanes.
+    // Three phases per stream, claimed separately by the workers: PRIME (writer, the first kPrime blocks staged, hashed
+    // and queued on the GPU), REST (the remaining samples) and FINISH (wait for the hash and the frames, metadata).
+    // A worker primes as long as fewer than kOpen streams are open, then takes the oldest primed stream's rest, then
+    // finishes the oldest submitted one -- so every stream's MD5 chain (26 ms for 512 frames of 24-bit stereo: the
+    // burst's floor) starts within the first millisecond and never runs dry, whatever the thread count.  (One stream
+    // per worker from start to end had 16 workers take 64 streams in four rounds of 28 ms, and 64 workers on a
+    // 16-CPU quota burn twice the CPU time and meet the throttle; without the priming the last of a worker's four
+    // streams started its hash 4.5-5 ms into the call.)  kOpen = the shared MD5 engines' lanes.
     constexpr size_t kOpen = 64;
+    constexpr size_t kPrime = kDirectFrames;   // blocks: the smallest write that is encoded without staging
     std::mutex claim_mu;
-    size_t next = 0, next_fin = 0;
+    size_t next = 0, next_rest = 0, next_fin = 0;
     std::vector<std::unique_ptr<flacenc_writer>> open_writers(n_jobs);
-    std::unique_ptr<std::atomic<int>[]> submitted(new std::atomic<int>[n_jobs ? n_jobs : 1]);
+    std::unique_ptr<std::atomic<int>[]> stage(new std::atomic<int>[n_jobs ? n_jobs : 1]);   // 1 primed, 2 submitted
     std::vector<double> t_start(n_jobs, 0.0);
-    for (size_t i = 0; i < n_jobs; i++) submitted[i].store(0, std::memory_order_relaxed);
+    std::vector<size_t> primed(n_jobs, 0);   // samples the first phase took
+    for (size_t i = 0; i < n_jobs; i++) stage[i].store(0, std::memory_order_relaxed);
     const double t_begin = now_ms();
-    auto submit = [&](size_t i) {
+    auto prime = [&](size_t i) {
         flacenc_job &j = jobs[i];
         j.out_len = 0;
         t_start[i] = now_ms();
@@ -1328,15 +1332,27 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
         w->kind = flacenc_writer::SAMPLE;
         w->use_fixed_sink(j.out, j.out_cap);
         int rc = w->init(*opts, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
-        if (!rc) rc = w->write_direct(j.samples, j.count);
+        const size_t head = kPrime * static_cast<size_t>(opts->block_size) * j.channels;
+        if (!rc && opts->shared_md5 && j.count >= 2 * head) {
+            rc = w->write_direct(j.samples, head);
+            primed[i] = head;
+        }
         j.status = rc;
         j.start_ms = t_start[i] - t_begin;
         if (!rc) open_writers[i] = std::move(w);
     };
-    auto finish = [&](size_t i) {
-        while (submitted[i].load(std::memory_order_acquire) == 0) std::this_thread::yield();   // (its submitter is at work)
-        std::unique_ptr<flacenc_writer> w = std::move(open_writers[i]);
+    auto rest = [&](size_t i) {
+        while (stage[i].load(std::memory_order_acquire) < 1) std::this_thread::yield();   // (being primed)
+        flacenc_writer *w = open_writers[i].get();
         if (!w) return;   // rejected or failed in its first phase: status says so
+        flacenc_job &j = jobs[i];
+        j.status = w->write_direct(j.samples + primed[i], j.count - primed[i]);
+        if (j.status) open_writers[i].reset();
+    };
+    auto finish = [&](size_t i) {
+        while (stage[i].load(std::memory_order_acquire) < 2) std::this_thread::yield();   // (its rest is at work)
+        std::unique_ptr<flacenc_writer> w = std::move(open_writers[i]);
+        if (!w) return;
         flacenc_job &j = jobs[i];
         j.status = w->finalize();
         j.out_len = w->sink.fixed_len;
@@ -1348,22 +1364,28 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
     auto work = [&]() {
         for (;;) {
             size_t idx;
-            bool do_submit;
+            int what;
             {
                 std::lock_guard<std::mutex> lock(claim_mu);
                 if (next < n_jobs && next - next_fin < kOpen) {
-                    do_submit = true;
+                    what = 0;
                     idx = next++;
-                } else if (next_fin < next) {
-                    do_submit = false;
+                } else if (next_rest < next) {
+                    what = 1;
+                    idx = next_rest++;
+                } else if (next_fin < next_rest) {
+                    what = 2;
                     idx = next_fin++;
                 } else {
                     return;   // everything claimed
                 }
             }
-            if (do_submit) {
-                submit(idx);
-                submitted[idx].store(1, std::memory_order_release);
+            if (what == 0) {
+                prime(idx);
+                stage[idx].store(1, std::memory_order_release);
+            } else if (what == 1) {
+                rest(idx);
+                stage[idx].store(2, std::memory_order_release);
             } else {
                 finish(idx);
             }
