@@ -14,7 +14,9 @@ if len(sys.argv) > 1:   # "streams,threads,batch,depth ..."
     CASES = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
 for n_streams, threads, batch, depth in CASES:
     be = BatchEncoder(Options.best().batch_frames(batch).pipeline_depth(depth), threads=threads)
-    streams = [per] * n_streams
+    # PROBE_DISTINCT=1: every stream its own array (1 GB of source PCM for 64 streams: the staging reads DRAM, as in the
+    # bench), otherwise one array 64 times (the staging reads cache)
+    streams = [per.copy() for _ in range(n_streams)] if os.environ.get('PROBE_DISTINCT') else [per] * n_streams
     be.encode(streams, 48000, 24, 2, copy=False)
     ts = []
     def throttled():
