@@ -708,14 +708,17 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // Independent channels, interleaved, with LPC: k_autocorr4's producers split the batch into the planar rows while
     // they read it (Params::split_src) -- the K0 pass (8 B per sample at the HBM roofline) disappears.  Needs every
     // frame on the wave kernels (no generic-path frame reads the rows before the autocorrelation has written them).
-    const bool split = !direct && !packed_bytes && layout == FLACGPU_LAYOUT_INTERLEAVED && !c->stereo4 &&
-                       c->channels >= 2 && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 &&
+    // (one channel: the input is its own planar row -- nothing to split, but the ORs still come out of the
+    // autocorrelation instead of a k_orbits pass over the batch)
+    const bool split = !direct && !packed_bytes && (layout == FLACGPU_LAYOUT_INTERLEAVED || c->channels == 1) && !c->stereo4 &&
+                       c->channels >= 1 && (c->channels >= 2 || planar_direct) && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 &&
                        B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
                        !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
                          c->knobs.ac_private || c->knobs.experiment_mfma_ac);
     if (split) {
         p.split_src = d_pcm;
-        p.split_dst = c->d_planar;
+        p.split_dst = c->channels == 1 ? nullptr : c->d_planar;
+        if (c->channels == 1) p.planar = d_pcm;   // [frame][B] with ldb == B (planar_direct)
     }
     if (!direct && !split) begin(0);
     bool have_orbits = direct || split;

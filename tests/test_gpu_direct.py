@@ -269,7 +269,9 @@ def test_independent_channels_split_inside_the_autocorrelation(monkeypatch):
 
 
 def test_mono_is_read_in_place(monkeypatch):
-    """One channel: the interleaved buffer is the planar row -- analysed without the K0 copy (an OR pass only)."""
+    """One channel: the interleaved buffer is the planar row -- analysed without the K0 copy; with LPC the ORs for the
+    wasted bits come out of the autocorrelation as well (no pass of its own over the batch), without LPC from k_orbits;
+    wasted bits, a silent frame and FLACGPU_NO_DIRECT (the copying path) give the same bytes."""
     from flac_codec_amd.gpu import GpuAnalyzer
 
     monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
@@ -285,4 +287,25 @@ def test_mono_is_read_in_place(monkeypatch):
     an.pack_device(7, 44100)
     res, _ = an.verify_device(44100, 7)
     assert (res.frames, res.bad_structure, res.bad_crc16) == (n, 0, 0)
+    an.set_timing(True)
+    an.analyze(pcm, n, B)
+    assert "k_deinterleave" not in an.kernel_ms()       # neither a copy nor an OR pass
     an.close()
+    x = (synth_fast(941, 1, 16, B * 5).astype(np.int64) << 3).astype(np.int32)   # three wasted bits
+    x[B:2 * B] = 0
+    outs = []
+    for lpc in (12, 0):
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("FLACGPU_NO_DIRECT", env)
+            else:
+                monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+            a2 = GpuAnalyzer(B, 6, lpc, True, True, 2, 0.5, 24, 1, max_frames=5)
+            outs.append(a2.encode_frames(x, 5, B, 0, 48000))
+            a2.close()
+        assert outs[-1] == outs[-2]
+        oo = orc_options_for(B, 6, lpc, True, True)
+        d2, o2 = outs[-1]
+        for f in range(5):
+            rc, fb, _ = orc.encode_frame(oo, 48000, 24, x[f * B:(f + 1) * B].reshape(1, B), frame_number=f)
+            assert rc == 0 and d2[o2[f]:o2[f + 1]] == fb, (lpc, f)
