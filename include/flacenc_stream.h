@@ -173,10 +173,13 @@ typedef struct {
     size_t out_len;           /* out: bytes of the finished stream */
     int32_t status;           /* out: FLACENC_OK or the error of this stream */
     int32_t reserved1;
-    /* out, diagnostics: wall time of this stream on its worker, and inside it the staging
+    /* out, diagnostics: wall time of this stream from its first phase to its last, and inside it the staging
      * (sample packing), the GPU calls incl. waiting for results, and the MD5 thread's busy time */
     double elapsed_ms, pack_ms, gpu_ms, md5_ms, start_ms;
 } flacenc_job;
+/* `threads` workers (0: half the hardware threads) share the streams' three phases -- first blocks, remaining samples,
+ * finish --, at most 64 streams open at a time: the thread count need not match the stream count (a few threads per
+ * usable CPU are enough), every stream's MD5 chain starts at once.  Returns the first failing stream's status. */
 int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads);
 
 /* FlacStreamWriter (encode.rs:1050-1290): header-less subset frames, parameters per call. */
