@@ -110,3 +110,76 @@ def synth_fast(seed, channels, bps, n):
     for c in range(channels):
         out[c::channels] = chans[c].astype(np.int32)
     return out
+
+
+def _resonator_bank(rng, sections, rate_frac=(0.01, 0.45), radius=(0.90, 0.985), real_pole=False):
+    """`sections` two-pole resonators with Q15 coefficients (a1 = 2 r cos(w), a2 = -r^2, both rounded to Q15):
+    the poles of an AR(2 * sections) process.  Frequencies are spread over the band (one per equal slice, jittered)
+    so that every section adds prediction gain of its own."""
+    out = []
+    lo, hi = rate_frac
+    for k in range(sections):
+        f = lo + (hi - lo) * (k + rng.uniform(0.15, 0.85)) / sections
+        r = rng.uniform(*radius)
+        a1 = int(round(2.0 * r * np.cos(2.0 * np.pi * f) * 32768.0))
+        a2 = int(round(-r * r * 32768.0))
+        out.append((a1, a2))
+    if real_pole:   # one real pole more: an odd model order
+        out.append((int(round(rng.choice([-1.0, 1.0]) * rng.uniform(0.6, 0.9) * 32768.0)), 0))
+    return out
+
+
+STEREO_MODES = ("corr", "indep", "anti", "near")
+
+
+def synth_hi(seed, channels, bps, n, sections=6, segment=4096 * 8, modes=STEREO_MODES, orders=None):
+    """High-order test/bench input: every channel is white noise through a CASCADE of `sections`
+    Q15 two-pole resonators -- an AR(2 * sections) process, which the reference's order estimate (encode.rs:3656-3702)
+    answers with LPC orders near 2 * sections instead of synth()'s order 2 -- scaled to bps - 3 bits, rounded to integers,
+    plus +-1 LSB dither.  The pole set and the number of sections (sections - sections // 3 .. sections) change every
+    `segment` samples (so frames differ in their coefficients and orders), and
+    so does the relation of an odd channel to the even one before it (`modes`: 3/4 correlated, independent,
+    anti-correlated, nearly equal), so that more than one channel assignment wins.  Vectorised (scipy lfilter in f64 on
+    integer-valued input); deterministic for a given numpy/scipy and only ever used as INPUT.  `orders`: the AR model
+    order of segment s is orders[s % len(orders)] (a real pole is added for odd ones) -- the tap-count coverage test."""
+    from scipy.signal import lfilter
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lo, hi = -(1 << (bps - 1)), (1 << (bps - 1)) - 1
+    target = float(1 << max(bps - 4, 2))
+    nseg = (n + segment - 1) // segment
+
+    def process(m, k):
+        e = rng.integers(-32768, 32769, size=m + 512).astype(np.float64)
+        y = e
+        for a1, a2 in _resonator_bank(rng, k // 2, real_pole=bool(k & 1)):
+            y = lfilter([1.0], [1.0, -a1 / 32768.0, -a2 / 32768.0], y)
+        y = y[512:]                                   # the filters' start-up transient
+        rms = float(np.sqrt(np.mean(y * y))) or 1.0
+        return np.rint(y * (target / rms)).astype(np.int64)
+
+    chans = [np.empty(n, dtype=np.int64) for _ in range(channels)]
+    for s in range(nseg):
+        a, b = s * segment, min(n, (s + 1) * segment)
+        m = b - a
+        mode = modes[int(rng.integers(0, len(modes)))]
+        # the segment's model order: 2 * (sections - sections // 3 .. sections) poles
+        k = 2 * int(rng.integers(sections - sections // 3, sections + 1))
+        if orders is not None:     # the caller names the model order of every segment (any order, odd ones too)
+            k = int(orders[s % len(orders)])
+        for c in range(channels):
+            y = process(m, k)
+            if c % 2 == 1:
+                left = chans[c - 1][a:b]
+                if mode == "corr":
+                    y = ((3 * left) >> 2) + (y >> 1)
+                elif mode == "anti":
+                    y = -((7 * left) >> 3) + (y >> 3)
+                elif mode == "near":
+                    y = left + (y >> 6)
+            y = y + rng.integers(-1, 2, size=m, dtype=np.int64)
+            chans[c][a:b] = np.clip(y, lo, hi)
+    out = np.empty(n * channels, dtype=np.int32)
+    for c in range(channels):
+        out[c::channels] = chans[c].astype(np.int32)
+    return out

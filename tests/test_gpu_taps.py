@@ -1,0 +1,79 @@
+"""Every tap-count instantiation of the in-place FIR is hit by a parity case.
+
+The candidate kernels (`k_cand64p` / `k_cand64`, kernels/wave_cand_lpc.inc) and the frame assembly (`k_frame64`,
+kernels/pack.inc) switch on the LPC order of a subframe into FIR instantiations of 2, 4, ... 16 taps (20, 24, 28, 32
+above order 16, 4096-sample blocks only).  The usual test signals make the reference's order estimate
+(encode.rs:3656-3702) choose a few orders only, so here every frame is an AR(k) process with k cycling over
+1..max order (tests/_pcm.py synth_hi(orders=...)): the ORACLE's plans must show every order among the winning
+subframes and more than one channel assignment, and the HIP path must give the oracle's bytes frame by frame --
+at every wave block length, through the in-place (DIRECT) kernels and through the planar-row ones."""
+import collections
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import synth_hi
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(monkeypatch, B, bps, max_lpc, channels=2, reps=3, seed=77, rate=48000, direct=(True, False)):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    orders = list(range(1, max_lpc + 1))
+    n = len(orders) * reps
+    pcm = synth_hi(seed, channels, bps, B * n, segment=B, orders=orders)
+    oopts = orc_options_for(B, 6, max_lpc, True, True)
+    first = 3
+    expect = []
+    won = collections.Counter()
+    assignments = collections.Counter()
+    for f, planar in enumerate(planar_frames(pcm, channels, B)):
+        rc, fb, plan = orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)
+        assert rc == 0
+        expect.append(fb)
+        assignments[plan.assignment] += 1
+        for c in range(channels):
+            if plan.sub[c].type == orc.SUB_LPC:
+                won[plan.sub[c].order] += 1
+    # the oracle's plans: every order wins somewhere, and (stereo) more than one channel assignment occurs
+    assert sorted(won) == orders, f"block {B}: orders without a winning subframe: {sorted(set(orders) - set(won))}"
+    if channels == 2:
+        assert len(assignments) > 1, assignments
+    for d in direct:
+        if d:
+            monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("FLACGPU_NO_DIRECT", "1")
+        an = GpuAnalyzer(B, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n)
+        data, off = an.encode_frames(pcm, n, B, first, rate)
+        for f in range(n):
+            assert data[off[f]:off[f + 1]] == expect[f], f"block {B} direct={d}: frame {f} differs from the oracle"
+        an.analyze(pcm, n, B)
+        an.pack_device(first, rate)
+        res, _ = an.verify_device(rate, first)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+        an.close()
+    return won, assignments
+
+
+@pytest.mark.parametrize("B", [1024, 1152, 2048, 2304, 4096])
+def test_orders_1_to_16_at_every_wave_block_length(monkeypatch, B):
+    """SPL 16 / 18 / 32 / 36 / 64 (k_cand64p<SPL,16>, k_cand64<SPL,16>, k_frame64<128,SPL,16>): orders 1..16."""
+    run_case(monkeypatch, B, 24, 16)
+
+
+def test_orders_1_to_32_at_4096(monkeypatch):
+    """k_cand64p<64,32> / k_frame64<128,64,32> and the deep autocorrelation: orders 1..32, the 20/24/28/32-tap FIRs."""
+    won, _ = run_case(monkeypatch, 4096, 24, 32, reps=2, rate=96000)
+    assert all(won[k] for k in range(17, 33))
+
+
+def test_orders_16_bit_and_independent_channels(monkeypatch):
+    """16-bit stereo (other bounds in fir_cannot_overflow), and 3 independent channels (k_cand64<64,16,false>,
+    k_frame64<192>): orders 1..16 again."""
+    run_case(monkeypatch, 4096, 16, 16, reps=2, seed=78, rate=44100)
+    run_case(monkeypatch, 4096, 24, 16, channels=3, reps=2, seed=79)
+    run_case(monkeypatch, 4096, 24, 12, channels=8, reps=2, seed=80, rate=192000, direct=(True,))
