@@ -55,13 +55,23 @@ CONFIGS = {
                  "32, partition order 6)"),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
+F64_PEAK_GFLOPS = 78600.0   # f64 vector peak as stated (FMA = 2 flop); separately rounded mul + add: half of it
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4   # wave64 instructions / s at the nominal clock
 
 
-def make_pcm(seed, frames, channels, bps):
-    from _pcm import synth_fast
+HI_SECTIONS = {3: 6, 4: 6, 5: 16}    # resonator sections of the high-order input per config (AR(2 x sections))
 
-    base = synth_fast(seed, channels, bps, BLOCK * min(DISTINCT, frames))
+
+def make_pcm(seed, frames, channels, bps, signal="ar2", sections=6):
+    """signal "ar2": SURVEY.md 8(d)'s generator (one 2-pole resonator: the encoder answers with LPC order 2);
+    "hi": tests/_pcm.py synth_hi, cascaded resonators whose model order changes every 8 frames (orders 8-12 with 6
+    sections, 22-32 with 16) together with the relation between the channels."""
+    from _pcm import synth_fast, synth_hi
+
+    if signal == "hi":
+        base = synth_hi(seed, channels, bps, BLOCK * min(DISTINCT, frames), sections=sections)
+    else:
+        base = synth_fast(seed, channels, bps, BLOCK * min(DISTINCT, frames))
     reps = (frames + DISTINCT - 1) // DISTINCT
     return np.tile(base, reps)[: frames * BLOCK * channels]
 
@@ -313,6 +323,11 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
 
 
 
+SIGNAL_TEXT = {"ar2": "SURVEY 8(d) generator: one Q15 2-pole resonator per channel + dither (the encoder answers with LPC order 2)",
+               "hi": "tests/_pcm.py synth_hi: AR(<= %d) -- cascaded Q15 resonators, model order and channel relation changing "
+                     "every 8 frames, +-1 LSB dither"}
+ASSIGNMENT_NAMES = {0: "independent", 8: "left_side", 9: "side_right", 10: "mid_side"}
+SUBFRAME_NAMES = {0: "constant", 1: "verbatim", 2: "fixed", 3: "lpc"}
 KERNEL_PROFILE_NAMES = {"k_autocorr": "k_autocorr4", "k_deinterleave": "k_deinterleave2", "k_pack": "k_frame64",
                         "k_cand64": "k_cand64p"}
 
@@ -322,7 +337,8 @@ class Workload:
     streams, each reading ITS OWN device buffer of synthetic PCM (a streaming encoder never re-reads its input:
     distinct buffers keep one context's batch out of the Infinity Cache of the next)."""
 
-    def __init__(self, torch, cfg_id, frames, first_frame, contexts, device, seed_rank, lag_split=0, pcm=None):
+    def __init__(self, torch, cfg_id, frames, first_frame, contexts, device, seed_rank, lag_split=0, pcm=None,
+                 signal="ar2"):
         from flac_codec_amd.gpu import GpuAnalyzer
 
         self.torch = torch
@@ -332,7 +348,9 @@ class Workload:
         self.F, self.first_frame = frames, first_frame
         # context i encodes its own PCM (seed differs); `pcm` given: every context the caller's samples (strong
         # scaling: the rank's range of ONE stream)
-        self.pcm = [pcm if pcm is not None else make_pcm(1000 + 16 * cfg_id + seed_rank + 101 * i, frames, self.C, self.BPS)
+        self.signal = signal
+        self.pcm = [pcm if pcm is not None else make_pcm(1000 + 16 * cfg_id + seed_rank + 101 * i, frames, self.C, self.BPS,
+                                                         signal, HI_SECTIONS.get(cfg_id, 6))
                     for i in range(contexts)]
         self.d_pcm = [torch.from_numpy(p).cuda() for p in self.pcm]
         self.ans = [GpuAnalyzer(BLOCK, self.PO, self.LPC, True, True, 2, 0.5, self.BPS, self.C, max_frames=frames,
@@ -395,6 +413,7 @@ class Workload:
         compressed = None
         verify = None
         C = self.C
+        self.order_histogram, self.assignment_histogram, self.subframe_types = {}, {}, {}
         for i, an in enumerate(self.ans):
             # one more batch from the context's own buffer through the timed entry point (the A/B loops after the
             # timed region may have left another buffer's frames in it)
@@ -407,7 +426,16 @@ class Workload:
             pcm = self.pcm[i]
             for f in range(check):
                 planar = np.ascontiguousarray(pcm[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
-                rc, fb, _ = orc.encode_frame(oopts, self.RATE, self.BPS, planar, frame_number=self.first_frame + f)
+                rc, fb, plan = orc.encode_frame(oopts, self.RATE, self.BPS, planar, frame_number=self.first_frame + f)
+                if rc == 0:    # what the ORACLE decided for this frame: winning subframes by type and LPC order
+                    a = ASSIGNMENT_NAMES.get(plan.assignment, str(plan.assignment))
+                    self.assignment_histogram[a] = self.assignment_histogram.get(a, 0) + 1
+                    for c in range(C):
+                        sp = plan.sub[c]
+                        t = SUBFRAME_NAMES[sp.type]
+                        self.subframe_types[t] = self.subframe_types.get(t, 0) + 1
+                        if sp.type == 3:
+                            self.order_histogram[sp.order] = self.order_histogram.get(sp.order, 0) + 1
                 if rc != 0 or data[off[f]:off[f + 1]] != fb:
                     differ += 1
                     if not experiment:
@@ -460,6 +488,9 @@ class Workload:
         }
 
     def kernels_report(self, compressed_bytes):
+        """Per-kernel durations priced against each kernel's own bound: HBM bytes for the integer kernels, separately
+        rounded f64 mul+add for the autocorrelation (no FMA is allowed there: 39.3 TFLOP/s is what the f64 VALU can
+        issue as mul + add; the datasheet's 78.6 TFLOP/s counts an FMA as two)."""
         acc = self.kernel_times()
         alg = self.algorithmic(compressed_bytes)
         kernels = {}
@@ -467,16 +498,21 @@ class Workload:
             entry = {"ms": round(ms, 4)}
             if k in alg:
                 kind, amount = alg[k]
-                entry["GB/s" if kind == "hbm" else "GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+                if kind == "hbm":
+                    entry["GB/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+                    entry["hbm_roofline_frac"] = round(entry["GB/s"] / HBM_PEAK_GBS, 4)
+                else:
+                    entry["GFLOP/s"] = round(amount / (ms * 1e-3) / 1e9, 1)
+                    entry["f64_frac_of_78.6_TF"] = round(entry["GFLOP/s"] / F64_PEAK_GFLOPS, 4)
+                    entry["f64_frac_of_39.3_TF_mul_add"] = round(entry["GFLOP/s"] / (F64_PEAK_GFLOPS / 2), 4)
             kernels[k] = entry
-        hbm = {k: v for k, v in kernels.items() if "GB/s" in v}
-        # dominant kernel = the longest launch; launches within 3 % of it count as tied (run-to-run noise decides their
-        # order) and the tie goes to the one with the larger algorithmic traffic
-        longest = max(v["ms"] for v in hbm.values())
-        tied = [k for k, v in hbm.items() if v["ms"] >= 0.97 * longest]
-        dom = max(tied, key=lambda k: alg[k][1])
-        for k, v in hbm.items():
-            v["hbm_roofline_frac"] = round(v["GB/s"] / HBM_PEAK_GBS, 4)
+        priced = {k: v for k, v in kernels.items() if k in alg}
+        # dominant kernel = the longest launch among the priced kernels (HBM- and f64-priced alike); launches within 3 %
+        # of it count as tied (run-to-run noise decides their order) and the tie goes to an HBM-priced kernel, then to
+        # the larger algorithmic amount
+        longest = max(v["ms"] for v in priced.values())
+        tied = [k for k, v in priced.items() if v["ms"] >= 0.97 * longest]
+        dom = max(tied, key=lambda k: (alg[k][0] == "hbm", alg[k][1]))
         return kernels, dom, alg
 
     def close(self):
@@ -485,57 +521,118 @@ class Workload:
         self.d_pcm = None
 
 
-def profile_figures(cfg_id, dom, dom_ms):
+def roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale):
+    """The `roofline` object of the dominant kernel, with the bound that prices it."""
+    kind, amount = alg[dom]
+    k = kernels[dom]
+    if kind == "hbm":
+        r = {"kernel": dom, "bound": "hbm", "achieved": k["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(k["GB/s"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+             "algorithmic_bytes": amount}
+    else:
+        r = {"kernel": dom, "bound": "f64-valu", "achieved": round(k["GFLOP/s"] / 1e3, 3), "peak": F64_PEAK_GFLOPS / 1e3,
+             "unit": "TFLOP/s", "frac": round(k["GFLOP/s"] / F64_PEAK_GFLOPS, 4),
+             "frac_of_mul_add_peak_39.3": round(k["GFLOP/s"] / (F64_PEAK_GFLOPS / 2), 4),
+             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops": amount,
+             "note": "exact left-fold autocorrelation: separately rounded f64 mul and add on the VALU (an FMA or a matrix "
+                     "core would change the sums); 78.6 TFLOP/s is the stated f64 peak, 39.3 what mul + add can reach"}
+    r["avg_launch_ms"] = k["ms"]
+    r["dominance_rule"] = ("longest launch among the priced kernels (HBM bytes or f64 flops); launches within 3 % are tied, "
+                           "an HBM-priced kernel wins a tie (every kernel's own fraction is in kernels.*)")
+    r["counters_stale"] = stale
+    if valu:
+        r["valu_issue"] = valu     # the integer kernels are bound by VALU instruction issue, not by HBM
+    return r
+
+
+def running_build_id():
+    from flac_codec_amd import _lib
+
+    return _lib.build_id()
+
+
+def profile_figures(cfg_id, dom, dom_ms, signal="ar2"):
     """HBM bytes and VALU instructions per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
     this same command (tools/collect_profiles.sh; corrected as MI355X_MICROARCH.md prescribes) -- deterministic
-    for a given input and workload -- and the instruction-issue floor of tools/issue_floor.py."""
+    for a given input, workload AND BUILD -- and the instruction-issue floor of tools/issue_floor.py.  Every collection
+    carries the build id of the library it was taken with (`_build_id`, flacgpu_build_id); the fourth value returned is
+    True when any figure used comes from a collection of ANOTHER build than the running library (or of an unknown
+    one): the counters next to this run's times are then stale."""
+    import re
+
     traffic = traffic_src = valu = None
-    tag = "" if cfg_id == 3 else f"cfg{cfg_id}_"
+    variant = ("" if cfg_id == 3 else f"cfg{cfg_id}") + ("hi" if signal == "hi" else "")
+    pat = r"^r\d+_" + (variant if variant else "[a-z]") + "_%s\\.json$"
     pdir = os.path.join(ROOT, "profiles")
     key = KERNEL_PROFILE_NAMES.get(dom, dom)
+    mine = running_build_id()
+    stale = False
+
+    def newest(kind):
+        names = sorted(f for f in os.listdir(pdir) if re.match(pat % kind, f))
+        if not names:
+            return None, None
+        return names[-1], json.load(open(os.path.join(pdir, names[-1])))
+
     try:
-        prof = sorted(f for f in os.listdir(pdir) if f.endswith("_traffic.json") and (("cfg" in f) == bool(tag)) and tag in f)
-        t = json.load(open(os.path.join(pdir, prof[-1])))
+        name, t = newest("traffic")
         k2 = key if key in t else (key[:-1] if key.endswith("p") and key[:-1] in t else None)
         if k2:
             traffic = t[k2]["hbm_bytes"]
-            traffic_src = {"source": "profiles/" + prof[-1], "kernel": k2,
+            traffic_src = {"source": "profiles/" + name, "kernel": k2, "build_id": t.get("_build_id"),
                            "fetch_bytes": t[k2].get("fetch_bytes"), "write_bytes": t[k2].get("write_bytes")}
+            stale |= t.get("_build_id") != mine
     except Exception:
         pass
     try:
-        vprof = sorted(f for f in os.listdir(pdir) if f.endswith("_valu.json") and (("cfg" in f) == bool(tag)) and tag in f)
-        vt = json.load(open(os.path.join(pdir, vprof[-1])))
+        name, vt = newest("valu")
         k2 = key if key in vt else (key[:-1] if key.endswith("p") and key[:-1] in vt else None)
         if k2 and vt[k2].get("SQ_INSTS_VALU"):
             insts = vt[k2]["SQ_INSTS_VALU"]
-            valu = {"wave_insts_per_launch": insts, "source": "profiles/" + vprof[-1],
+            valu = {"wave_insts_per_launch": insts, "source": "profiles/" + name, "build_id": vt.get("_build_id"),
                     "achieved_Ginst/s": round(insts / (dom_ms * 1e-3) / 1e9, 1),
                     "nominal_peak_Ginst/s": round(VALU_ISSUE_PEAK / 1e9, 1),
                     "frac_of_nominal_4_cycle_peak": round(insts / (dom_ms * 1e-3) / VALU_ISSUE_PEAK, 4),
                     "valu_active_per_wave_cycle": vt[k2].get("valu_active_per_wave_cycle"),
                     "note": "the 4-cycle peak is a model; attainable_ms below is the floor from the kernel's own "
                             "instruction mix at MEASURED per-class issue costs (profiles/r03_issue_rate_ubench.json)"}
+            stale |= vt.get("_build_id") != mine
     except Exception:
         pass
     try:
-        fl = json.load(open(os.path.join(pdir, "r03_issue_floor.json")))
-        e = fl.get(f"config{cfg_id}", {}).get(dom)
+        floors = sorted(f for f in os.listdir(pdir) if re.match(r"^r\d+_issue_floor\.json$", f))
+        fl = json.load(open(os.path.join(pdir, floors[-1])))
+        e = fl.get(f"config{cfg_id}" + ("hi" if signal == "hi" else ""), {}).get(dom)
         if e and valu is not None:
             valu["attainable_ms"] = e["attainable_ms"]
-            valu["attainable_source"] = "profiles/r03_issue_floor.json (tools/issue_floor.py)"
+            valu["attainable_source"] = f"profiles/{floors[-1]} (tools/issue_floor.py)"
+            valu["attainable_build_id"] = fl.get("_build_id")
             valu["frac_of_attainable"] = round(e["attainable_ms"] / dom_ms, 4)
+            stale |= fl.get("_build_id") != mine
     except Exception:
         pass
-    return traffic, traffic_src, valu
+    if traffic is None and valu is None:
+        stale = None      # nothing read from a collection
+    return traffic, traffic_src, valu, stale
 
 
-def measure_other_config(torch, cfg_id, args, device, orc):
-    """A BASELINE configuration that is not the headline one, at its SURVEY 8(d) size: ms/step over `steps` timed steps
-    of the same multi-context loop, every context's distinct frames against the oracle, the dominant kernel and its
-    recomputed roofline fraction."""
+def histogram_summary(w, cfg_id):
+    """What the oracle decided for the distinct frames of every context (Workload.parity)."""
+    subs = sum(w.subframe_types.values()) or 1
+    orders = {str(k): v for k, v in sorted(w.order_histogram.items())}
+    at_least = 20 if cfg_id == 5 else 8
+    return {"order_histogram": orders, "subframe_types": w.subframe_types, "channel_assignments": w.assignment_histogram,
+            "winning_subframes": subs,
+            f"frac_of_winning_subframes_at_lpc_order_>={at_least}":
+                round(sum(v for k, v in w.order_histogram.items() if k >= at_least) / subs, 4)}
+
+
+def measure_other_config(torch, cfg_id, args, device, orc, signal="ar2"):
+    """A BASELINE configuration that is not the headline one (or the headline one on another input signal), at its SURVEY
+    8(d) size: ms/step over `steps` timed steps of the same multi-context loop, every context's distinct frames against
+    the oracle (with the histogram of the oracle's decisions), the dominant kernel and its recomputed roofline fraction."""
     t_wall = time.perf_counter()
-    w = Workload(torch, cfg_id, args.frames, 0, args.contexts, device, 0)
+    w = Workload(torch, cfg_id, args.frames, 0, args.contexts, device, 0, signal=signal)
     pre = w.prewarm(200.0)
     for _ in range(3):
         w.step()
@@ -543,18 +640,19 @@ def measure_other_config(torch, cfg_id, args, device, orc):
     el = w.timed(steps)
     ms = el / steps * 1e3
     ok, identical, differ, compressed, verify = w.parity(orc)
-    assert ok, f"config {cfg_id}: parity check failed"
+    assert ok, f"config {cfg_id} ({signal}): parity check failed"
     kernels, dom, alg = w.kernels_report(compressed)
-    traffic, traffic_src, valu = profile_figures(cfg_id, dom, kernels[dom]["ms"])
+    traffic, traffic_src, valu, stale = profile_figures(cfg_id, dom, kernels[dom]["ms"], signal)
     cfg = w.cfg
-    out = {"workload": cfg["text"], "level": cfg["level"], "frames_per_step": w.F, "contexts": len(w.ans), "steps": steps,
+    out = {"workload": cfg["text"], "level": cfg["level"], "signal": SIGNAL_TEXT[signal] if signal != "hi" else
+           SIGNAL_TEXT[signal] % (2 * HI_SECTIONS.get(cfg_id, 6)),
+           "frames_per_step": w.F, "contexts": len(w.ans), "steps": steps,
            "ms_per_step": round(ms, 4), "Msamples/s": round(w.F * BLOCK * w.C / (ms * 1e-3) / 1e6, 1),
            "prewarm_steps": pre,
            "frames_byte_identical_to_oracle": identical, "frames_checked": identical + differ,
            "frames_round_tripped_on_device": w.F * len(w.ans),
-           "dominant_kernel": {"kernel": dom, "avg_launch_ms": kernels[dom]["ms"], "algorithmic_bytes": alg[dom][1],
-                               "achieved_GB/s": kernels[dom]["GB/s"], "frac": round(kernels[dom]["GB/s"] / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "traffic_source": traffic_src, "valu_issue": valu},
+           "oracle_decisions": histogram_summary(w, cfg_id),
+           "dominant_kernel": roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale),
            "kernels": kernels,
            "compression_ratio": round(compressed / (w.F * BLOCK * w.C * ((w.BPS + 7) // 8)), 4)}
     w.close()
@@ -583,6 +681,10 @@ def main():
     ap.add_argument("--emit-flac", default=None,
                     help="strong scaling: rank 0 writes the whole .flac (frames gathered from the ranks, metadata rebuilt "
                          "from the gathered sizes) to this path")
+    ap.add_argument("--signal", choices=("ar2", "hi"), default="ar2",
+                    help="input signal of the headline loop: ar2 = SURVEY 8(d)'s generator (the contract; LPC order 2 wins "
+                         "everywhere), hi = tests/_pcm.py synth_hi (high LPC orders win) -- for profile collections of "
+                         "`variants.high_order_input`; the default line reports both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -654,7 +756,8 @@ def main():
         total_frames = args.frames
     else:
         F, first_frame = args.frames, rank * args.frames      # contiguous frame ranges per GPU (8(e))
-        w = Workload(torch, args.config, F, first_frame, args.contexts, local_rank, rank, args.lag_split)
+        w = Workload(torch, args.config, F, first_frame, args.contexts, local_rank, rank, args.lag_split,
+                     signal=args.signal)
         total_frames = F * world
     an = w.ans[0]
 
@@ -742,19 +845,11 @@ def main():
                         "candidates_compared": mf["compared"],
                         "candidates_whose_quantised_lpc_params_change": mf["params_differ"],
                         "note": "re-associated sums are not the reference's left fold; kept off the product path"}
-        achieved = kernels[dom]["GB/s"]
-        traffic = traffic_src = valu = None
+        traffic = traffic_src = valu = stale = None
         if F == FRAMES:
-            traffic, traffic_src, valu = profile_figures(args.config, dom, kernels[dom]["ms"])
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "algorithmic_bytes": alg[dom][1], "avg_launch_ms": kernels[dom]["ms"],
-                    "dominance_rule": "longest launch; launches within 3 % of it are tied and the larger algorithmic "
-                                      "traffic wins (every HBM-priced kernel's own fraction is in kernels.*.hbm_roofline_frac)"}
-        if valu:
-            # the integer kernels are bound by VALU instruction issue, not by HBM
-            roofline["valu_issue"] = valu
+            traffic, traffic_src, valu, stale = profile_figures(args.config, dom, kernels[dom]["ms"], args.signal)
+        roofline = roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale)
+        headline_decisions = histogram_summary(w, args.config)
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -770,6 +865,14 @@ def main():
             for cid in sorted(CONFIGS):
                 if cid != args.config:
                     others[f"config{cid}"] = measure_other_config(torch, cid, args, local_rank, orc)
+                    if cid == 5:
+                        # the order-32 configuration on an input that makes the encoder choose orders >= 20
+                        others[f"config{cid}"]["high_order_input"] = measure_other_config(torch, cid, args, local_rank, orc,
+                                                                                          signal="hi")
+            if CONFIGS[args.config]["lpc"] and args.signal == "ar2":
+                # the headline configuration on an input on which the encoder chooses HIGH LPC orders (SURVEY's generator
+                # makes it choose order 2 everywhere: `value` times a 2-tap FIR)
+                variants["high_order_input"] = measure_other_config(torch, args.config, args, local_rank, orc, signal="hi")
         out = {
             "metric": metric_text(args.config, differ == 0),
             "value": round(value, 2),
@@ -783,7 +886,9 @@ def main():
             "vs_baseline": None,
             "dtype": "i32/i64 (+f64 LPC analysis)",
             "data": "synthetic",
-            "config": {"workload": f"config {args.config}: {cfg['text']}; "
+            "config": {"signal": SIGNAL_TEXT[args.signal] if args.signal != "hi" else
+                       SIGNAL_TEXT["hi"] % (2 * HI_SECTIONS.get(args.config, 6)),
+                       "workload": f"config {args.config}: {cfg['text']}; "
                                    + (f"ONE stream of {total_frames} frames per step cut into contiguous frame ranges over "
                                       f"{world} rank(s)" if strong else f"{F} frames per GPU per step")
                                    + f", PCM resident in HBM, frame bytes produced in HBM; consecutive batches rotate "
@@ -800,6 +905,8 @@ def main():
             "end_to_end": e2e,
             "other_configs": others,
             "kernels": kernels,
+            "oracle_decisions": headline_decisions,
+            "build_id": running_build_id(),
             "mfma_autocorr_experiment": mfma_exp,
             "device_verify": verify,
             "compression_ratio": round(compressed_bytes / (F * BLOCK * C * ((BPS + 7) // 8)), 4),

@@ -94,6 +94,8 @@ class GpuStats(C.Structure):
         ("order_ties", C.c_uint32),
         ("log2_edge", C.c_uint32),
         ("order_ties_resolved", C.c_uint32),
+        ("fir_recheck", C.c_uint32),
+        ("fir_rechecked", C.c_uint32),
     ]
 
 
@@ -174,7 +176,34 @@ def _load():
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]
     L.flacgpu_kernel_name.restype = C.c_char_p
+    L.flacgpu_build_id.argtypes = []
+    L.flacgpu_build_id.restype = C.c_char_p
     return L
+
+
+def build_id():
+    """flacgpu_build_id() of the loaded library (hash of the sources it was built from)."""
+    return lib().flacgpu_build_id().decode()
+
+
+def source_build_id():
+    """The same hash computed from the sources in the tree (None when they are not there): differs from build_id()
+    when the library is stale."""
+    import hashlib
+
+    src = os.path.join(_HERE, "csrc")
+    files = []
+    for sub, pat in (("", ".hip"), ("host", ""), ("kernels", "")):
+        d = os.path.join(src, sub)
+        if not os.path.isdir(d):
+            return None
+        files += [os.path.join(sub, f) for f in os.listdir(d)
+                  if f.endswith(pat) and os.path.isfile(os.path.join(d, f))]
+    files.append("Makefile")
+    h = hashlib.sha256()
+    for f in sorted(files):      # make's $(sort): byte order
+        h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def exported_symbols():

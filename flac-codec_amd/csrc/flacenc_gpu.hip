@@ -64,6 +64,7 @@ Knobs read_knobs() {
     auto on = [](const char *name) { return getenv(name) != nullptr; };
     k.no_direct = on("FLACGPU_NO_DIRECT");
     k.no_cand_pair = on("FLACGPU_NO_CAND_PAIR");
+    k.force_fir_check = on("FLACGPU_FIR_CHECK");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
     k.no_w64 = on("FLACGPU_NO_W64");
@@ -85,6 +86,7 @@ Knobs read_knobs() {
         if (const char *e = getenv("FLACGPU_TIE_BAND")) { k.has_tie_band = true; k.tie_band = atof(e); }
         if (const char *e = getenv("FLACGPU_TIE_PERTURB")) { k.has_tie_perturb = true; k.tie_perturb = atof(e); }
         if (const char *e = getenv("FLACGPU_DECODE_LANES")) k.decode_lanes = (uint32_t)atoi(e);
+        if (const char *e = getenv("FLACGPU_FIR_SUSPECT_BITS")) k.fir_suspect_bits = (uint32_t)atoi(e);
     }
     return k;
 }
@@ -121,6 +123,8 @@ struct flacgpu_ctx {
     Knobs knobs;                  // the FLACGPU_* environment, read once at flacgpu_create
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
     uint32_t ties_resolved = 0;     // candidates re-decided on the host for the last analysis
+    uint32_t fir_rechecked = 0;     // candidate waves of the last analysis that asked for the checked FIR re-run
+                                    // (Params::check_fir) and got it
     uint32_t last_n_fast = 0;       // frames of the last analysis that took the wave kernels
     uint64_t last_first_frame = 0;  // arguments of the last frame assembly (re-run after a re-decision)
     uint32_t last_rate = 0;
@@ -570,7 +574,8 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.tie_cap = c->max_frames * c->ncand;
     p.tie_band = c->tie_band;
     p.tie_perturb = c->tie_perturb;
-
+    p.check_fir = c->knobs.force_fir_check ? 1u : 0u;
+    p.fir_suspect_bits = c->knobs.fir_suspect_bits ? c->knobs.fir_suspect_bits : 30u;
 }
 
 // stream == NULL: the context's own (non-blocking) stream, ordered AFTER whatever the caller has
@@ -802,6 +807,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->last_n_fast = pf.fcount;
     c->ties_checked = !lpc;
     c->ties_resolved = 0;
+    c->fir_rechecked = 0;
     // the residual rows (k_emit) are produced lazily: flacgpu_fetch(residuals) / host packing
     // need them, the device-side packer recomputes residuals in registers instead
     c->resid_valid = false;
@@ -840,11 +846,17 @@ static int resolve_order_ties(flacgpu_ctx *c) {
     if (int rc = copy_sync(c, s, c->d_stats, sizeof s, hipMemcpyDeviceToHost)) return rc;
     const uint32_t cap = c->max_frames * c->ncand;
     const uint32_t n_ties = std::min(s[1], cap);
-    if (n_ties == 0) return FLACGPU_OK;
+    // s[3]: candidate waves whose unchecked FIR could not rule a ResidualOverflow out (Params::check_fir)
+    const bool recheck_fir = s[3] != 0;
+    if (n_ties == 0 && !recheck_fir) return FLACGPU_OK;
     static_assert(sizeof(flacenc::HostLpc) == sizeof(LpcParams), "same record on both sides");
     std::vector<uint32_t> list(n_ties);
     if (int rc = copy_sync(c, list.data(), c->d_ties, sizeof(uint32_t) * n_ties, hipMemcpyDeviceToHost)) return rc;
-    const Params p = c->last_params;
+    Params p = c->last_params;
+    if (recheck_fir) {
+        p.check_fir = 1;   // the candidate stage below tests every FIR exactly (fir64_overflows)
+        c->fir_rechecked = s[3];
+    }
     const size_t nc = (size_t)p.n_frames * p.ncand;
     std::vector<double> ac;
     std::vector<CandInfo> ci;
@@ -1157,6 +1169,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     c->last_n_fast = n_frames;
     c->ties_checked = !lpc;
     c->ties_resolved = 0;
+    c->fir_rechecked = 0;
     c->last_first_frame = first_frame_number;
     c->last_rate = sample_rate;
     return FLACGPU_OK;
@@ -1598,7 +1611,7 @@ int flacgpu_frames_ready(flacgpu_ctx *c, const uint64_t **offsets, uint64_t *tot
     CTX_GUARD(c);
     if (int rc = wait_waitable(c, c->ev_sizes)) return rc;
     if (!c->ties_checked) {
-        if (c->h_stats[1] == 0) {
+        if (c->h_stats[1] == 0 && c->h_stats[3] == 0) {
             c->ties_checked = true;   // the common case: nothing to re-decide, nothing to wait for
         } else {                      // order ties: host re-decision, then the sizes again
             if (int rc = resolve_order_ties(c)) return rc;
@@ -1635,7 +1648,7 @@ int flacgpu_fetch_frames_async(flacgpu_ctx *c, uint8_t *out, size_t cap) {
         return FLACGPU_OK;
     }
     c->prev_total = bytes;
-    if (c->early_bytes && out == c->early_dst && c->ties_resolved == 0) {
+    if (c->early_bytes && out == c->early_dst && c->ties_resolved == 0 && c->fir_rechecked == 0) {
         // the early copy (queued behind the kernels at submission) holds the first early_bytes; the rest now
         if (bytes > c->early_bytes) {
             g_early_remainders.fetch_add(1, std::memory_order_relaxed);
@@ -1813,6 +1826,8 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     out->order_ties = s[1];
     out->log2_edge = s[2];
     out->order_ties_resolved = c->ties_resolved;
+    out->fir_recheck = s[3];
+    out->fir_rechecked = c->fir_rechecked;
     return FLACGPU_OK;
 }
 

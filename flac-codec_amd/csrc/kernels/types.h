@@ -92,6 +92,13 @@ struct Params {
     uint32_t *tie_list;
     uint32_t tie_cap;
     double tie_band, tie_perturb;
+    // ResidualOverflow (encode.rs:3190-3197) in the wave kernels.  0 (every first analysis): the in-place FIR runs
+    // unchecked and the fold of its residual tells whether an overflow was POSSIBLE -- a wrapped x - pred of a <= 25-bit
+    // sample has magnitude >= 2^31 - 2^24, so a lane whose sum of folded residuals stays below 2^30 has none; a wave
+    // that cannot rule it out counts itself in stats[3] and the host has the candidate stage run again with
+    // check_fir = 1 (resolve_order_ties), where every candidate takes the exact read-only test fir64_overflows first.
+    uint32_t check_fir;
+    uint32_t fir_suspect_bits;   // 30; a TEST knob lowers it so that ordinary input exercises the re-run
 };
 
 
@@ -153,11 +160,13 @@ struct Knobs {
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
+    bool force_fir_check = false;       // A/B + TEST: every candidate takes the exact ResidualOverflow test first (FLACGPU_FIR_CHECK)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)
     bool has_tie_band = false, has_tie_perturb = false;
     double tie_band = 0.0, tie_perturb = 0.0;   // TEST
     uint32_t decode_lanes = 0;          // TEST: lanes per wave of the stand-alone decoder, 0: default
+    uint32_t fir_suspect_bits = 0;      // TEST: Params::fir_suspect_bits, 0: default (30)
 };
 Knobs read_knobs();   // flacenc_gpu.hip
 

@@ -122,6 +122,11 @@ typedef struct {
     uint32_t order_ties_resolved; /* of order_ties: candidates whose LPC parameters were recomputed on
                                    the host with its libm (encode.rs:3656-3702) before the results
                                    were handed out; every fetch / verify entry point does this */
+    uint32_t fir_recheck;       /* candidates whose LPC residual, computed WITHOUT the per-sample overflow test of
+                                   encode.rs:3190-3197, was too large to rule an overflow out (a lane's sum of
+                                   folded residuals >= 2^30: garbage predictions only) */
+    uint32_t fir_rechecked;     /* of fir_recheck: re-analysed with the exact test before the results were handed
+                                   out (the same entry points as order_ties_resolved) */
 } flacgpu_stats;
 
 typedef struct flacgpu_ctx flacgpu_ctx;
@@ -344,6 +349,11 @@ int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *ctx, float *kernel_ms, uint32_
 int flacgpu_set_timing(flacgpu_ctx *ctx, int enable);
 int flacgpu_get_kernel_ms(flacgpu_ctx *ctx, float ms[FLACGPU_N_KERNELS]);
 const char *flacgpu_kernel_name(int index);
+
+/* Identity of this build: the first 16 hex digits of the SHA-256 over the library's sources (every file under
+ * csrc/ but build/, in sorted path order: csrc/Makefile `BUILD_ID`).  Counter collections under profiles/ carry the
+ * id of the library they were taken with; bench.py prints `counters_stale` when it differs from the running one. */
+const char *flacgpu_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 COMMON="--contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 200 --no-other-configs"
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from flac_codec_amd import _lib; print(_lib.build_id())" > $OUT/build_id.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 $COMMON "$@" > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 $COMMON "$@" > $OUT/fetch.log 2>&1

@@ -29,6 +29,10 @@ def per_kernel(counter_dir, counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+try:
+    build_id = open(f"{src}/build_id.txt").read().strip()   # flacgpu_build_id() of the library the passes ran
+except FileNotFoundError:
+    build_id = None
 fetch = per_kernel("fetch", "FETCH_SIZE")
 write = per_kernel("write", "WRITE_SIZE")
 out = {}
@@ -37,7 +41,7 @@ for k in sorted(set(fetch) | set(write)):
     wb = write.get(k, 0.0) * 1024
     out[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb),
               "raw_FETCH_SIZE_KiB": fetch.get(k), "raw_WRITE_SIZE_KiB": write.get(k)}
-json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+json.dump({"_build_id": build_id, **out}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 # VALU issue counters (per launch, summed over the chip).  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES
 # count quad-cycles (MI355X_MICROARCH.md), SQ_INSTS_VALU counts wave-instructions.
 valu = {}
@@ -50,7 +54,7 @@ for k, v in valu.items():
     if v.get("SQ_INSTS_VALU") and v.get("SQ_WAVES"):
         v["valu_insts_per_wave"] = round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1)
 if valu:
-    json.dump(valu, open(f"profiles/{tag}_valu.json", "w"), indent=1)
+    json.dump({"_build_id": build_id, **valu}, open(f"profiles/{tag}_valu.json", "w"), indent=1)
 stats = sorted(glob.glob(f"{src}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]   # newest run only
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
