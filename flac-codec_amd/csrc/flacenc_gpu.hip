@@ -121,6 +121,8 @@ struct flacgpu_ctx {
     uint32_t *d_ties = nullptr;     // candidates whose LPC order estimates tie (k_lpc), [F * NC]
     double tie_band = 1e-9, tie_perturb = 0.0;
     Knobs knobs;                  // the FLACGPU_* environment, read once at flacgpu_create
+    bool env_no_direct = false;     // FLACGPU_NO_DIRECT as read at creation; copy_input: FLACGPU_TUNE_COPY_INPUT.  knobs.no_direct
+    bool copy_input = false;        //   is their OR
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
     uint32_t ties_resolved = 0;     // candidates re-decided on the host for the last analysis
     uint32_t fir_rechecked = 0;     // candidate waves of the last analysis that asked for the checked FIR re-run
@@ -472,6 +474,7 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_ties, F * NC);
     if (c->stereo4 && !o->exhaustive_channel_correlation) ALLOC(c->d_abs, F * 4);
     c->knobs = read_knobs();
+    c->env_no_direct = c->knobs.no_direct;
     if (c->knobs.has_tie_band) c->tie_band = c->knobs.tie_band;            // test knobs
     if (c->knobs.has_tie_perturb) c->tie_perturb = c->knobs.tie_perturb;
 #undef ALLOC
@@ -613,10 +616,11 @@ static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last
 // k_layout's tiles find each other through PackParams::tile_sync, whose words carry the launch's 24-bit epoch: a new
 // one per launch, the words wiped (in stream order) when the counter wraps
 static int next_layout_epoch(flacgpu_ctx *c, PackParams &q, hipStream_t st) {
-    c->layout_epoch = (c->layout_epoch + 1) & 0xFFFFFFu;
+    // (steps of 8: launch_layout cuts a launch of more than 256 tiles into chunks with epochs of their own)
+    c->layout_epoch = (c->layout_epoch + 8) & 0xFFFFF8u;
     if (c->layout_epoch == 0) {
         HIP_TRY(hipMemsetAsync(c->d_tile_sync, 0, sizeof(unsigned long long) * (c->max_frames / 1024 + 2), st));
-        c->layout_epoch = 1;
+        c->layout_epoch = 8;
     }
     q.tile_sync = c->d_tile_sync;
     q.epoch = c->layout_epoch;
@@ -1064,7 +1068,11 @@ int flacgpu_set_tuning(flacgpu_ctx *c, int key, int value) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     switch (key) {
     case FLACGPU_TUNE_TWO_RANGES: c->two_ranges = value != 0; return FLACGPU_OK;
-    case FLACGPU_TUNE_COPY_INPUT: c->knobs.no_direct = value != 0; return FLACGPU_OK;
+    case FLACGPU_TUNE_COPY_INPUT:
+        // its own flag: turning the tuning off must not cancel an environment FLACGPU_NO_DIRECT=1
+        c->copy_input = value != 0;
+        c->knobs.no_direct = c->env_no_direct || c->copy_input;
+        return FLACGPU_OK;
     case FLACGPU_TUNE_LAG_SPLIT:
         if (value != 2 && value != 4) break;
         c->lag_split = value;
@@ -1123,7 +1131,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     q.out_words = c->d_packed;
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
-    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0);
+    // (planar rows are read in place unless the caller asked for a copy: FLACGPU_TUNE_COPY_INPUT / FLACGPU_NO_DIRECT)
+    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && !c->knobs.no_direct;
     if (planar_direct) p.planar = d_pcm;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st0));  // + d_orbits
     HIP_TRY(hipEventRecord(c->ev_fork, st0));

@@ -1065,9 +1065,19 @@ namespace {
 // (which runs it too) and returns when all of them are done.  Threads are created on demand and never exit (a
 // detached, intentionally leaked pool: no joins during static destruction).
 struct WorkerPool {
+    // One run(): the work, and its completion state.  Shared (not on the caller's stack): a helper that has just
+    // reported completion may still be inside its call when run() returns (ADVICE r03 -- the mutex, the condition
+    // variable and the closure used to live in run()'s frame, and the last helper decremented the counter before it
+    // took the lock: run() could return, and its frame die, between those two steps).
+    struct Job {
+        std::function<void()> fn;
+        std::mutex m;
+        std::condition_variable cv;
+        unsigned left = 0;      // helpers that have not finished fn() yet; guarded by m
+    };
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<std::function<void()> *> tasks;
+    std::condition_variable cv_work;
+    std::deque<std::shared_ptr<Job>> tasks;
     unsigned idle = 0, total = 0;
     static WorkerPool &get() {
         static WorkerPool *p = new WorkerPool();
@@ -1079,35 +1089,33 @@ struct WorkerPool {
             idle++;
             cv_work.wait(lock, [&] { return !tasks.empty(); });
             idle--;
-            std::function<void()> *t = tasks.front();
+            std::shared_ptr<Job> job = std::move(tasks.front());
             tasks.pop_front();
             lock.unlock();
-            (*t)();
+            job->fn();
+            {   // the whole hand-off under the job's mutex; `job` keeps it alive past run()'s return
+                std::lock_guard<std::mutex> l(job->m);
+                if (--job->left == 0) job->cv.notify_all();
+            }
+            job.reset();
             lock.lock();
         }
     }
     template <class F>
     void run(unsigned helpers, F &fn) {
-        std::atomic<unsigned> left{helpers};
-        std::mutex dm;
-        std::condition_variable dcv;
-        std::function<void()> task = [&] {
-            fn();
-            if (left.fetch_sub(1) == 1) {
-                std::lock_guard<std::mutex> l(dm);
-                dcv.notify_all();
-            }
-        };
+        auto job = std::make_shared<Job>();
+        job->fn = [&fn] { fn(); };     // fn lives in the caller's frame: every call of it ends before `left` reaches 0
+        job->left = helpers;
         {
             std::lock_guard<std::mutex> lock(mu);
-            for (unsigned i = 0; i < helpers; i++) tasks.push_back(&task);
+            for (unsigned i = 0; i < helpers; i++) tasks.push_back(job);
             const unsigned need = helpers > idle ? helpers - idle : 0;
             for (unsigned i = 0; i < need && total < 1024; i++, total++) std::thread([this] { worker(); }).detach();
         }
         cv_work.notify_all();
         fn();
-        std::unique_lock<std::mutex> l(dm);
-        dcv.wait(l, [&] { return left.load() == 0; });
+        std::unique_lock<std::mutex> l(job->m);
+        job->cv.wait(l, [&] { return job->left == 0; });
     }
 };
 }  // namespace
@@ -1285,7 +1293,15 @@ size_t flacenc_worst_case_bytes(const flacenc_options *opts, uint32_t bits_per_s
     // (a side channel), rounded up; one 18-byte seek point per frame at most; fLaC + STREAMINFO (4 + 38), block headers,
     // the vendor comment and the padding
     const uint64_t frame_bytes = 18 + channels * 2 + (B * channels * (bits_per_sample + 1) + 7) / 8;
-    const uint64_t meta = 42 + 3 * 4 + 64 + (opts->padding > 0 ? (uint64_t)opts->padding : 0);
+    // VORBIS_COMMENT as the writer emits it (metadata/mod.rs:2010-2139): vendor length + vendor + field count + (length +
+    // field) per field -- the caller's strings, whatever their size
+    uint64_t vorbis = 0;
+    if (opts->n_comment_fields || opts->vendor_string) {
+        vorbis = 4 + (opts->vendor_string ? std::strlen(opts->vendor_string) : 16) + 4;
+        for (uint32_t i = 0; i < opts->n_comment_fields; i++)
+            vorbis += 4 + (opts->comment_fields && opts->comment_fields[i] ? std::strlen(opts->comment_fields[i]) : 0);
+    }
+    const uint64_t meta = 42 + 3 * 4 + 64 + vorbis + (opts->padding > 0 ? (uint64_t)opts->padding : 0);
     return (size_t)(frames * (frame_bytes + 18) + meta + 64);
 }
 

@@ -3,6 +3,7 @@
 // 3834-3907, 2408-2409; crc.rs:99-188.
 // One of the translation units of libflacenc_amd.so (gfx950 only; built with -ffp-contract=off, see
 // Makefile); the kernels are reached through the launchers declared in kernels/types.h.
+#include <algorithm>
 #include "kernels/types.h"
 
 #include <stdlib.h>
@@ -24,7 +25,19 @@ void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t f
     else launch_frame64_short(p, q, B, frames, lds, st);                   // <= 4 channels
 }
 void launch_layout(const Params &p, const PackParams &q, hipStream_t st) {
-    hipLaunchKernelGGL(k_layout, dim3((p.fcount + 1023) / 1024), dim3(1024), 0, st, p, q);
+    // <= 256 tiles per launch (all of them resident at once: the look-back needs no dispatch order); more frames
+    // continue from frame_off[f0] in the next launch of the same stream, with an epoch of their own (the context hands
+    // out epochs in steps of 8: up to 2 M frames per call)
+    constexpr uint32_t kMaxTiles = 256;
+    Params r = p;
+    PackParams e = q;
+    for (uint32_t done = 0; done < p.fcount || done == 0; done += kMaxTiles * 1024u) {
+        r.f0 = p.f0 + done;
+        r.fcount = std::min(p.fcount - done, kMaxTiles * 1024u);
+        hipLaunchKernelGGL(k_layout, dim3((r.fcount + 1023) / 1024), dim3(1024), 0, st, r, e);
+        e.epoch++;
+        if (p.fcount == 0) break;
+    }
 }
 void launch_zero(const PackParams &q, uint32_t n_frames, hipStream_t st) {
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(WG), 0, st, q, n_frames);
