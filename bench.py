@@ -318,6 +318,12 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         out["encode_frames_pcie_inclusive"]["pinned_8192_frames_Msamples/s"] = round(
             whole.size / statistics.median(big_times[1:]) / 1e6, 1)
     big.close()
+    import torch
+
+    # the same leg with both link directions in flight (flacgpu_pipeline_*): two batch sizes
+    out["pipelined_pcie"] = pipelined_pcie(torch, cfg, pcm, device, orc, 2048, depth=4, batches=16)
+    out["pipelined_pcie"]["batch_8192"] = {k: v for k, v in pipelined_pcie(torch, cfg, pcm, device, orc, FRAMES, depth=3,
+                                                                            batches=6).items() if k not in ("link", "note")}
     return out
 
 
@@ -328,6 +334,89 @@ SIGNAL_TEXT = {"ar2": "SURVEY 8(d) generator: one Q15 2-pole resonator per chann
                      "every 8 frames, +-1 LSB dither"}
 ASSIGNMENT_NAMES = {0: "independent", 8: "left_side", 9: "side_right", 10: "mid_side"}
 SUBFRAME_NAMES = {0: "constant", 1: "verbatim", 2: "fixed", 3: "lpc"}
+def pcie_probe(torch, mib=256):
+    """Host <-> device copy rates of this box with pinned memory (tools/pcie_probe.py, same run): each direction alone
+    and both together (GB/s; `both` is the SUM of the two directions while they run at the same time)."""
+    n = mib << 20
+    h = [torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    d = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    ss = [torch.cuda.Stream() for _ in range(2)]
+
+    def run(h2d, d2h):
+        best = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            if h2d:
+                with torch.cuda.stream(ss[0]):
+                    d[0].copy_(h[0], non_blocking=True)
+            if d2h:
+                with torch.cuda.stream(ss[1]):
+                    h[1].copy_(d[1], non_blocking=True)
+            torch.cuda.synchronize()
+            best = max(best, n * (int(h2d) + int(d2h)) / (time.perf_counter() - t) / 1e9)
+        return best
+
+    return {"h2d_GB/s": round(run(True, False), 1), "d2h_GB/s": round(run(False, True), 1),
+            "both_directions_at_once_sum_GB/s": round(run(True, True), 1)}
+
+
+def pipelined_pcie(torch, cfg, pcm, device, orc, batch_frames, depth=4, batches=12):
+    """The full-duplex host -> host batch loop (flacgpu_pipeline_*, include/flacenc_gpu.h; what encode.rs:558-585 drives):
+    pinned host PCM -> finished frames in pinned host memory, `depth` contexts in rotation, no MD5.  Both upload widths:
+    int32 samples (4 B) and the stream-width little-endian samples (3 B at 24 bits).  Output checked against the
+    synchronous call."""
+    from flac_codec_amd.gpu import GpuAnalyzer, PinnedBuffer, Pipeline
+
+    C, bps, rate = cfg["ch"], cfg["bps"], cfg["rate"]
+    link = pcie_probe(torch)
+    out = {"link": link, "batch_frames": batch_frames, "depth": depth, "batches_timed": batches}
+    F = min(batch_frames, pcm.size // (BLOCK * C))
+    batch = np.ascontiguousarray(pcm[: F * BLOCK * C])
+    an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=F, device=device)
+    ref_bytes, ref_off = an.encode_frames(batch, F, BLOCK, 0, rate)
+    an.close()
+    width = (bps + 7) // 8
+    le = np.ascontiguousarray(batch.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width]).reshape(-1)
+    down = len(ref_bytes) / batch.size
+    for name, bpsam, src in (("int32", 4, batch.view(np.uint8)), (f"packed_{width}_byte", width, le)):
+        pipe = Pipeline(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=F, depth=depth, device=device)
+        bufs = [PinnedBuffer(src.size) for _ in range(depth)]
+        for b in bufs:
+            b.array[:] = src
+        # first round: every slot once (context warm-up), checked against the synchronous call
+        for i in range(depth):
+            assert pipe.submit(bufs[i].address, bpsam, F, BLOCK, 0, rate)
+        for i in range(depth):
+            data, off = pipe.retire()
+            assert data == ref_bytes and off == ref_off, f"pipelined {name} batch differs from flacgpu_encode_frames"
+        best = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(batches):
+                if pipe.in_flight() == depth:
+                    pipe.retire(copy=False)
+                assert pipe.submit(bufs[i % depth].address, bpsam, F, BLOCK, 0, rate)
+            while pipe.in_flight():
+                pipe.retire(copy=False)
+            best = max(best, batches * batch.size / (time.perf_counter() - t) / 1e6)
+        pipe.close()
+        for b in bufs:
+            b.close()
+        # what the link allows: each direction alone, and the two together when they share one ceiling
+        lim = min(link["h2d_GB/s"] / bpsam, link["d2h_GB/s"] / down, link["both_directions_at_once_sum_GB/s"] / (bpsam + down))
+        lim_fd = min(link["h2d_GB/s"] / bpsam, link["d2h_GB/s"] / down)
+        out[name] = {"Msamples/s": round(best, 1), "bytes_up_per_sample": bpsam, "bytes_down_per_sample": round(down, 3),
+                     "link_GB/s_used_up": round(best * bpsam / 1e3, 1), "link_GB/s_used_down": round(best * down / 1e3, 1),
+                     "link_limit_Msamples/s": round(lim * 1e3, 1), "frac_of_link": round(best / (lim * 1e3), 4),
+                     "frac_of_full_duplex_link": round(best / (lim_fd * 1e3), 4), "byte_identical_to_synchronous_call": True}
+    out["note"] = ("best of 3 loops of `batches` batches through flacgpu_pipeline_submit / _retire; link_limit = min(h2d / bytes up, "
+                   "d2h / bytes down, both-at-once sum / (bytes up + down)) with the copy rates measured in this run; "
+                   "frac_of_full_duplex_link ignores the third term")
+    return out
+
+
 KERNEL_PROFILE_NAMES = {"k_autocorr": "k_autocorr4", "k_deinterleave": "k_deinterleave2", "k_pack": "k_frame64",
                         "k_cand64": "k_cand64p"}
 

@@ -176,6 +176,19 @@ def _load():
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     L.flacgpu_kernel_name.argtypes = [C.c_int]
     L.flacgpu_kernel_name.restype = C.c_char_p
+    L.flacgpu_packed_cap.argtypes = [vp]
+    L.flacgpu_packed_cap.restype = C.c_size_t
+    L.flacgpu_pipeline_create.argtypes = [C.POINTER(GpuOptions), C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
+                                          C.POINTER(vp)]
+    L.flacgpu_pipeline_destroy.argtypes = [vp]
+    L.flacgpu_pipeline_destroy.restype = None
+    L.flacgpu_pipeline_submit.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.flacgpu_pipeline_retire.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_uint64)),
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.flacgpu_pipeline_in_flight.argtypes = [vp]
+    L.flacgpu_pipeline_in_flight.restype = C.c_uint32
+    L.flacgpu_pipeline_depth.argtypes = [vp]
+    L.flacgpu_pipeline_depth.restype = C.c_uint32
     L.flacgpu_build_id.argtypes = []
     L.flacgpu_build_id.restype = C.c_char_p
     return L

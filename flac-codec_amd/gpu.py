@@ -313,3 +313,85 @@ def host_pack_frames(sample_rate, bits_per_sample, channels, first_frame_number,
     if rc:
         raise RuntimeError(f"flacenc_pack_frames: {rc}")
     return buf.tobytes(), list(off)
+
+
+class PinnedBuffer:
+    """Pinned host memory from flacgpu_host_alloc, viewed as a numpy uint8 array (`.array`)."""
+
+    def __init__(self, nbytes):
+        self._p = _lib.lib().flacgpu_host_alloc(nbytes)
+        if not self._p:
+            raise MemoryError("flacgpu_host_alloc")
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    @property
+    def address(self):
+        return self._p
+
+    def close(self):
+        if self._p:
+            self.array = None
+            _lib.lib().flacgpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pipeline:
+    """flacgpu_pipeline_* (include/flacenc_gpu.h): `depth` encoder contexts taking consecutive batches in rotation --
+    upload of batch n, kernels of n - 1 and the frames of n - 2 in flight together.  PCM comes from PINNED buffers
+    (PinnedBuffer) and must stay untouched until its batch has been retired."""
+
+    def __init__(self, block_size, max_partition_order, max_lpc_order, mid_side, exhaustive, window_kind, window_param,
+                 bits_per_sample, channels, max_frames, depth=4, device=-1):
+        L = _lib.lib()
+        o = GpuOptions(block_size, max_partition_order, max_lpc_order or 0, int(bool(mid_side)),
+                       int(bool(exhaustive)), window_kind, 0, window_param)
+        self._h = C.c_void_p(None)
+        rc = L.flacgpu_pipeline_create(C.byref(o), bits_per_sample, channels, device, max_frames, depth, C.byref(self._h))
+        if rc:
+            raise GpuError(rc, "flacgpu_pipeline_create")
+        self.depth = depth
+
+    def in_flight(self):
+        return _lib.lib().flacgpu_pipeline_in_flight(self._h)
+
+    def submit(self, pinned_address, bytes_per_sample, n_frames, last_frame_len, first_frame_number, sample_rate):
+        """Returns False (nothing queued) when every slot holds a batch: retire() first."""
+        rc = _lib.lib().flacgpu_pipeline_submit(self._h, C.c_void_p(pinned_address), bytes_per_sample, n_frames,
+                                                last_frame_len, first_frame_number, sample_rate)
+        if rc == -6:
+            return False
+        if rc:
+            raise GpuError(rc, "flacgpu_pipeline_submit")
+        return True
+
+    def retire(self, copy=True):
+        """The oldest batch in flight: (frame bytes, offsets[n_frames + 1]); with copy=False a (address, total,
+        offsets pointer, n_frames) tuple valid until the next submit."""
+        frames = C.c_void_p(None)
+        off = C.POINTER(C.c_uint64)()
+        n = C.c_uint32(0)
+        total = C.c_uint64(0)
+        rc = _lib.lib().flacgpu_pipeline_retire(self._h, C.byref(frames), C.byref(off), C.byref(n), C.byref(total))
+        if rc:
+            raise GpuError(rc, "flacgpu_pipeline_retire")
+        if not copy:
+            return frames.value, total.value, off, n.value
+        return C.string_at(frames.value, total.value), [off[i] for i in range(n.value + 1)]
+
+    def close(self):
+        if self._h:
+            _lib.lib().flacgpu_pipeline_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

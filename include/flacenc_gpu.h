@@ -48,7 +48,8 @@ enum {
                                      encode.rs:3756/3880) */
     FLACGPU_ERR_HIP = -3,         /* HIP runtime failure; flacgpu_last_error() has the text */
     FLACGPU_ERR_NO_DEVICE = -4,
-    FLACGPU_ERR_BUFFER_TOO_SMALL = -5
+    FLACGPU_ERR_BUFFER_TOO_SMALL = -5,
+    FLACGPU_ERR_BUSY = -6         /* flacgpu_pipeline_submit: every slot holds a batch, retire one first */
 };
 
 /* encode.rs:1713-1720 `Window` */
@@ -285,6 +286,31 @@ int flacgpu_encode_packed_async_host(flacgpu_ctx *ctx, const uint8_t *pcm_le, ui
 size_t flacgpu_packed_cap(const flacgpu_ctx *ctx);   /* bytes a batch of max_frames frames can need */
 int flacgpu_fetch_frames_async(flacgpu_ctx *ctx, uint8_t *out, size_t cap);
 int flacgpu_wait(flacgpu_ctx *ctx);
+
+/* ---- the pipelined batch loop: host PCM in, finished frames in host memory out, both link directions busy ----------
+ * Replaces the per-block loop of `Encoder::encode` as FlacSampleWriter::write drives it (encode.rs:558-585) for callers
+ * that bring whole batches of blocks and do their own stream bookkeeping: `depth` encoder contexts take consecutive
+ * batches in rotation, each on its own HIP stream, so the upload of batch n, the kernels of batch n - 1 and the frames of
+ * batch n - 2 (stored by k_frame64 straight into the slot's pinned buffer) are in flight together.
+ *   submit   queues H2D + analysis + frame assembly of one batch and returns at once; FLACGPU_ERR_BUSY when all `depth`
+ *            slots hold a batch.  `pcm`: interleaved samples in PINNED host memory (flacgpu_host_alloc), int32 when
+ *            bytes_per_sample == 4, else the little-endian ceil(bps / 8)-byte samples of flacgpu_encode_packed_async;
+ *            it must stay valid until that batch has been retired.
+ *   retire   waits for the OLDEST batch in flight and hands out its frames: `*frames` (pinned memory owned by the
+ *            pipeline), `*offsets` (n_frames + 1 byte offsets) and `*total` stay valid until the next submit, which
+ *            reuses that slot.  Frames are byte-identical to flacgpu_encode_frames on the same batch.
+ * Batches are independent (frame numbers come from the caller), so the output order is the submit order.
+ * examples/c_abi_pipeline.c is the whole recipe; bench.py's end_to_end.pipelined_pcie measures it. */
+typedef struct flacgpu_pipeline flacgpu_pipeline;
+int flacgpu_pipeline_create(const flacgpu_options *opts, uint32_t bits_per_sample, uint32_t channels, int device,
+                            uint32_t max_frames, uint32_t depth, flacgpu_pipeline **out);
+void flacgpu_pipeline_destroy(flacgpu_pipeline *p);
+int flacgpu_pipeline_submit(flacgpu_pipeline *p, const void *pcm, uint32_t bytes_per_sample, uint32_t n_frames,
+                            uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate);
+int flacgpu_pipeline_retire(flacgpu_pipeline *p, const uint8_t **frames, const uint64_t **offsets, uint32_t *n_frames,
+                            uint64_t *total);
+uint32_t flacgpu_pipeline_in_flight(const flacgpu_pipeline *p);
+uint32_t flacgpu_pipeline_depth(const flacgpu_pipeline *p);
 
 /* ---- device-side decode + verify of the frames packed last ----------
  * The reference's frame decoder (decode.rs:1388-1436 read_frame, 1494-1633 read_subframes,
