@@ -189,6 +189,7 @@ def _load():
     L.flacgpu_pipeline_in_flight.restype = C.c_uint32
     L.flacgpu_pipeline_depth.argtypes = [vp]
     L.flacgpu_pipeline_depth.restype = C.c_uint32
+    L.flacgpu_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.flacgpu_build_id.argtypes = []
     L.flacgpu_build_id.restype = C.c_char_p
     return L

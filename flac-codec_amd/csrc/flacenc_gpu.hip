@@ -65,6 +65,7 @@ Knobs read_knobs() {
     k.no_direct = on("FLACGPU_NO_DIRECT");
     k.no_cand_pair = on("FLACGPU_NO_CAND_PAIR");
     k.force_fir_check = on("FLACGPU_FIR_CHECK");
+    k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
     k.no_w64 = on("FLACGPU_NO_W64");
@@ -121,6 +122,7 @@ struct flacgpu_ctx {
     uint32_t *d_ties = nullptr;     // candidates whose LPC order estimates tie (k_lpc), [F * NC]
     double tie_band = 1e-9, tie_perturb = 0.0;
     Knobs knobs;                  // the FLACGPU_* environment, read once at flacgpu_create
+    const uint8_t *packed_src = nullptr;   // upload by kernel (Knobs::upload_by_kernel): K0 reads the caller's pinned PCM itself
     bool env_no_direct = false;     // FLACGPU_NO_DIRECT as read at creation; copy_input: FLACGPU_TUNE_COPY_INPUT.  knobs.no_direct
     bool copy_input = false;        //   is their OR
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
@@ -322,7 +324,8 @@ bool packed_k0_supported(uint32_t block_size, uint32_t channels, uint32_t bytes)
 template <int C>
 void launch_k0_packed_c(flacgpu_ctx *c, uint32_t bytes, const dim3 &grid, uint32_t n_frames, uint32_t last_len,
                         uint32_t f0, hipStream_t st) {
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(c->d_in);
+    const uint32_t *in = c->packed_src ? reinterpret_cast<const uint32_t *>(c->packed_src)
+                                       : reinterpret_cast<const uint32_t *>(c->d_in);
     const uint32_t B = c->opts.block_size;
     unsigned long long *abs = (C == 2 && c->d_abs && c->ncand == 4) ? c->d_abs : nullptr;   // (zeroed by the caller)
     switch (bytes) {
@@ -346,6 +349,9 @@ void launch_k0_packed(flacgpu_ctx *c, uint32_t bytes, uint32_t n_frames, uint32_
         default: break;
         }
     }
+}
+__global__ void __launch_bounds__(WG) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n16; i += (size_t)gridDim.x * WG) dst[i] = src[i];
 }
 void launch_orbits(const Params &p, uint32_t *orbits, hipStream_t st) {
     for (uint32_t f = p.f0; f < p.f0 + p.fcount; f += kGridY) {
@@ -1527,6 +1533,63 @@ void *flacgpu_host_alloc(size_t bytes) {
 void flacgpu_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
+// What the host link of `device` carries (GB/s, both directions summed): mode 0 = that direction idle, 1 = a copy engine
+// (hipMemcpyAsync on a stream of its own), 2 = a kernel loading from / storing to pinned host memory.  Best of 4 runs
+// of `bytes` each way.  A diagnostic for bench.py's end_to_end.pipelined_pcie (tools/ubench/pcie_duplex.hip is the
+// stand-alone form).
+int flacgpu_link_probe(int device, size_t bytes, int up_mode, int down_mode, double *sum_gbs) {
+    if (!sum_gbs || bytes < 4096 || up_mode < 0 || up_mode > 2 || down_mode < 0 || down_mode > 2 || (!up_mode && !down_mode))
+        return FLACGPU_ERR_INVALID_ARG;
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return FLACGPU_ERR_NO_DEVICE;
+    DeviceGuard guard(dev);
+    bytes &= ~(size_t)15;
+    void *h_up = nullptr, *h_down = nullptr, *d_up = nullptr, *d_down = nullptr;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    auto cleanup = [&] {
+        if (s0) (void)hipStreamDestroy(s0);
+        if (s1) (void)hipStreamDestroy(s1);
+        if (h_up) (void)hipHostFree(h_up);
+        if (h_down) (void)hipHostFree(h_down);
+        if (d_up) (void)hipFree(d_up);
+        if (d_down) (void)hipFree(d_down);
+    };
+    auto fail = [&](hipError_t e, const char *what) {
+        g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+        cleanup();
+        return FLACGPU_ERR_HIP;
+    };
+#define PROBE_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(e_, #x); } while (0)
+    PROBE_TRY(hipHostMalloc(&h_up, bytes, hipHostMallocDefault));
+    PROBE_TRY(hipHostMalloc(&h_down, bytes, hipHostMallocDefault));
+    PROBE_TRY(hipMalloc(&d_up, bytes));
+    PROBE_TRY(hipMalloc(&d_down, bytes));
+    memset(h_up, 1, bytes);
+    PROBE_TRY(hipMemset(d_down, 2, bytes));
+    PROBE_TRY(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+    PROBE_TRY(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    double best = 0.0;
+    for (int it = 0; it < 4; it++) {
+        PROBE_TRY(hipStreamSynchronize(s0));
+        PROBE_TRY(hipStreamSynchronize(s1));
+        const auto t = std::chrono::steady_clock::now();
+        if (up_mode == 1) PROBE_TRY(hipMemcpyAsync(d_up, h_up, bytes, hipMemcpyHostToDevice, s0));
+        if (up_mode == 2)
+            hipLaunchKernelGGL(k_copy16, dim3(256), dim3(WG), 0, s0, (const uint4 *)h_up, (uint4 *)d_up, bytes / 16);
+        if (down_mode == 1) PROBE_TRY(hipMemcpyAsync(h_down, d_down, bytes, hipMemcpyDeviceToHost, s1));
+        if (down_mode == 2)
+            hipLaunchKernelGGL(k_copy16, dim3(256), dim3(WG), 0, s1, (const uint4 *)d_down, (uint4 *)h_down, bytes / 16);
+        PROBE_TRY(hipStreamSynchronize(s0));
+        PROBE_TRY(hipStreamSynchronize(s1));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+        best = std::max(best, (double)bytes * ((up_mode != 0) + (down_mode != 0)) / dt / 1e9);
+    }
+#undef PROBE_TRY
+    cleanup();
+    *sum_gbs = best;
+    return FLACGPU_OK;
+}
+
 int flacgpu_current_device(void) {
     int d = -1;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
@@ -1579,10 +1642,22 @@ int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint
     hipStream_t st = c->own_stream;
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t bytes = ((size_t)(n_frames - 1) * B + last_len) * C * bytes_per_sample;
-    HIP_TRY(hipMemcpyAsync(c->d_in, pcm_le, bytes, hipMemcpyHostToDevice, st));
-    if (int rc = analyze_impl(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, st,
-                              bytes_per_sample == 4 ? 0 : bytes_per_sample))
-        return rc;
+    // The upward leg.  Default: a copy engine (hipMemcpyAsync).  FLACGPU_UPLOAD_KERNEL=1 (A/B, pinned memory only): the
+    // bytes cross the link as kernel loads -- K0 reads the stream-width samples straight out of the caller's pinned
+    // buffer; int32 samples take a copy kernel into d_in
+    c->packed_src = nullptr;
+    if (c->knobs.upload_by_kernel && bytes_per_sample != 4) {
+        c->packed_src = pcm_le;
+    } else if (c->knobs.upload_by_kernel) {
+        hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(WG), 0, st, reinterpret_cast<const uint4 *>(pcm_le),
+                           reinterpret_cast<uint4 *>(c->d_in), (bytes + 15) / 16);
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_in, pcm_le, bytes, hipMemcpyHostToDevice, st));
+    }
+    const int arc = analyze_impl(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, st,
+                                 bytes_per_sample == 4 ? 0 : bytes_per_sample);
+    c->packed_src = nullptr;
+    if (arc) return arc;
     // the frame sizes leave the device as soon as k_layout has run (second stream), so that the host
     // can size the copy of the bytes while k_frame64 is still assembling them
     c->host_out = (reinterpret_cast<uintptr_t>(out_host) & 3u) ? nullptr : out_host;

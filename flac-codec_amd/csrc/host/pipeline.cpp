@@ -8,6 +8,7 @@
 // stream bookkeeping use include/flacenc_stream.h; this is the batch boundary of include/flacenc_gpu.h made
 // overlap-by-default.  Built from the public entry points only (no HIP headers here).
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -25,6 +26,7 @@ struct flacgpu_pipeline {
     };
     std::vector<Slot> slots;
     uint32_t head = 0, tail = 0, in_flight = 0;   // submit at head, retire at tail
+    bool engine_down = false;   // A/B (FLACGPU_PIPELINE_ENGINE_DOWN=1): frames assembled in HBM, copied down by a copy engine
     std::string error;
 };
 
@@ -36,6 +38,7 @@ int flacgpu_pipeline_create(const flacgpu_options *opts, uint32_t bits_per_sampl
     flacgpu_pipeline *p = new (std::nothrow) flacgpu_pipeline();
     if (!p) return FLACGPU_ERR_HIP;
     p->slots.resize(depth);
+    if (const char *e = getenv("FLACGPU_PIPELINE_ENGINE_DOWN")) p->engine_down = e[0] && e[0] != '0';
     for (auto &s : p->slots) {
         int rc = flacgpu_create(opts, bits_per_sample, channels, device, max_frames, &s.ctx);
         if (rc == FLACGPU_OK) {
@@ -73,7 +76,8 @@ int flacgpu_pipeline_submit(flacgpu_pipeline *p, const void *pcm, uint32_t bytes
     if (p->in_flight == p->slots.size()) return FLACGPU_ERR_BUSY;   // retire one first
     flacgpu_pipeline::Slot &s = p->slots[p->head];
     const int rc = flacgpu_encode_packed_async_host(s.ctx, static_cast<const uint8_t *>(pcm), bytes_per_sample, n_frames,
-                                                    last_frame_len, first_frame_number, sample_rate, s.out, s.cap);
+                                                    last_frame_len, first_frame_number, sample_rate,
+                                                    p->engine_down ? nullptr : s.out, p->engine_down ? 0 : s.cap);
     if (rc != FLACGPU_OK) return rc;
     s.n_frames = n_frames;
     s.busy = true;

@@ -160,6 +160,7 @@ struct Knobs {
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
+    bool upload_by_kernel = false;      // A/B: the asynchronous host path reads the caller's pinned PCM with kernel loads (FLACGPU_UPLOAD_KERNEL)
     bool force_fir_check = false;       // A/B + TEST: every candidate takes the exact ResidualOverflow test first (FLACGPU_FIR_CHECK)
     uint32_t cand_grid = 0;             // resident workgroups of the persistent candidate kernels, 0: default
     bool experiment_mfma_ac = false;    // TEST: the re-associating MFMA autocorrelation (not bit-exact)

@@ -267,6 +267,11 @@ int flacgpu_pack_plans(flacgpu_ctx *ctx, const int32_t *pcm, uint32_t n_frames, 
 void *flacgpu_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc), NULL on failure */
 void flacgpu_host_free(void *p);
 int flacgpu_current_device(void);       /* the caller's current HIP device, -1 without one */
+/* Diagnostic: GB/s the host link of `device` (-1: current) carries, both directions summed, moving `bytes` each way with
+ * up_mode / down_mode = 0 (idle), 1 (copy engine: hipMemcpyAsync on its own stream) or 2 (a kernel loading from /
+ * storing to pinned host memory) at the same time.  The asynchronous host path uploads by copy engine and lets k_frame64
+ * store the frames into pinned memory: (1, 2) is its ceiling. */
+int flacgpu_link_probe(int device, size_t bytes, int up_mode, int down_mode, double *sum_gbs);
 /* 1 when flacgpu_encode_packed_async takes this sample width for the context's stream shape (a block
  * must be a whole number of 16-byte groups); otherwise widen to int32 and pass bytes_per_sample 4 */
 int flacgpu_packed_input_supported(const flacgpu_ctx *ctx, uint32_t bytes_per_sample);
