@@ -65,6 +65,7 @@ Knobs read_knobs() {
     k.no_direct = on("FLACGPU_NO_DIRECT");
     k.no_cand_pair = on("FLACGPU_NO_CAND_PAIR");
     k.force_fir_check = on("FLACGPU_FIR_CHECK");
+    k.no_sub64 = on("FLACGPU_NO_SUB64");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
@@ -151,6 +152,7 @@ struct flacgpu_ctx {
     uint32_t *d_packed = nullptr;   // packed frame bytes (as 32-bit words)
     uint64_t *d_frame_off = nullptr;
     unsigned long long *d_tile_sync = nullptr;   // k_layout's tile exchange (PackParams::tile_sync)
+    PackParams::SubEdgeRec *d_edges = nullptr;   // k_sub64: [F][C] edge records (5..8 channels)
     uint32_t layout_epoch = 0;
     uint64_t packed_cap = 0;        // bytes
     bool packed_valid = false;
@@ -476,6 +478,7 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_frame_off, F + 1);
     ALLOC(c->d_tile_sync, F / 1024 + 2);
     HIP_TRY(hipMemset(c->d_tile_sync, 0, sizeof(unsigned long long) * (F / 1024 + 2)));
+    if (channels >= 5 && !read_knobs().no_sub64) ALLOC(c->d_edges, F * channels);   // (c->knobs is filled further down)
     if (B > LDS_BLOCK_LIMIT) ALLOC(c->d_big, F * NC * (size_t)big_scratch_ints((uint32_t)B));
     ALLOC(c->d_ties, F * NC);
     if (c->stereo4 && !o->exhaustive_channel_correlation) ALLOC(c->d_abs, F * 4);
@@ -525,6 +528,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_tile_sync);
+    (void)hipFree(c->d_edges);
     (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify); (void)hipFree(c->d_big);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -630,6 +634,7 @@ static int next_layout_epoch(flacgpu_ctx *c, PackParams &q, hipStream_t st) {
     }
     q.tile_sync = c->d_tile_sync;
     q.epoch = c->layout_epoch;
+    q.edges = c->d_edges;
     return FLACGPU_OK;
 }
 

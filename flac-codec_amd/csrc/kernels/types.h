@@ -121,6 +121,9 @@ struct PackParams {
     // every launch, so the words are never reset
     unsigned long long *tile_sync = nullptr;
     uint32_t epoch = 0;
+    // k_sub64 (one workgroup per subframe, kernels/sub64.inc): the subframes' edge records [frame][channel], merged by
+    // k_sub_finish; nullptr: the frame-per-workgroup k_frame64 assembles every wave-kernel frame
+    struct SubEdgeRec { uint32_t w[8]; } *edges = nullptr;
 };
 
 // words reserved for a subframe's bit string: a chosen subframe is never longer than its
@@ -159,6 +162,7 @@ struct Knobs {
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
+         no_sub64 = false,         // A/B: frames of 3..8 channels assembled by one workgroup per FRAME (k_frame64) (FLACGPU_NO_SUB64)
          no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
     bool upload_by_kernel = false;      // A/B: the asynchronous host path reads the caller's pinned PCM with kernel loads (FLACGPU_UPLOAD_KERNEL)
     bool force_fir_check = false;       // A/B + TEST: every candidate takes the exact ResidualOverflow test first (FLACGPU_FIR_CHECK)
@@ -202,6 +206,8 @@ hipError_t pack_set_attributes(size_t pack_lds);
 void launch_frame64_4096(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_direct(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st);
 void launch_frame64_deep(const Params &p, const PackParams &q, uint32_t frames, size_t lds, hipStream_t st);
+// sub64.hip: one workgroup per subframe (independent channels, 4096-sample blocks, LPC order <= 16)
+void launch_sub64(const Params &p, const PackParams &q, uint32_t frames, hipStream_t st);
 void launch_frame64_short(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds,
                           hipStream_t st);
 // decode.hip

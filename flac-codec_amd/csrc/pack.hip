@@ -19,7 +19,8 @@ namespace {
 
 namespace flacgpu_k {
 void launch_frame64(const Params &p, const PackParams &q, uint32_t B, uint32_t frames, size_t lds, hipStream_t st) {
-    if (p.inter) launch_frame64_direct(p, q, B, frames, lds, st);             // 4096-sample stereo blocks read in place
+    if (q.edges && B == FN && p.channels >= 5 && !p.stereo4 && p.max_lpc_order <= 16) launch_sub64(p, q, frames, st);   // one workgroup per subframe (3, 4 channels: k_frame64 measured faster)
+    else if (p.inter) launch_frame64_direct(p, q, B, frames, lds, st);        // 4096-sample stereo blocks read in place
     else if (p.max_lpc_order > 16) launch_frame64_deep(p, q, frames, lds, st);   // 4096-sample blocks, <= 4 channels
     else if (B == FN) launch_frame64_4096(p, q, frames, lds, st);
     else launch_frame64_short(p, q, B, frames, lds, st);                   // <= 4 channels

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 --no-other-configs > $OUT/g$i.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-end-to-end --sustained-steps 0 --prewarm-ms 0 --no-other-configs $PMC_BENCH_ARGS > $OUT/g$i.log 2>&1
 done
 cd $ROOT
 python3 - $OUT <<'PY'
@@ -20,6 +20,6 @@ for f in glob.glob(out+"/g*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:58]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    if any(x in k for x in ("k_cand64","k_autocorr4","k_frame64","k_deinterleave2")):
+    if any(x in k for x in ("k_cand64","k_autocorr4","k_frame64","k_deinterleave2","k_sub64")):
         print(k, {c:round(sum(x)/len(x)) for c,x in v.items()})
 PY
