@@ -697,6 +697,29 @@ def profile_figures(cfg_id, dom, dom_ms, signal="ar2"):
     return traffic, traffic_src, valu, stale
 
 
+def batch_sweep(torch, cfg_id, args, device, sizes=(256, 512, 1024, 2048, 4096, 8192)):
+    """Step time by batch size (frames per flacgpu_encode_device call), the same multi-context loop: what many small
+    streams and a strong-scaled stream (frames / GPUs per rank) get.  per_sample_rate_vs_8192 = 1 means no small-batch
+    penalty."""
+    cfg = CONFIGS[cfg_id]
+    base = make_pcm(1000 + 16 * cfg_id, max(sizes), cfg["ch"], cfg["bps"])
+    rows = {}
+    for n in sizes:
+        w = Workload(torch, cfg_id, n, 0, args.contexts, device, 0, pcm=base[: n * BLOCK * cfg["ch"]])
+        w.prewarm(60.0)
+        steps = max(20, min(400, int(20 * 8192 / n)))
+        ms = w.timed(steps) / steps * 1e3
+        w.only_first = True
+        ms1 = w.timed(max(10, steps // 2)) / max(10, steps // 2) * 1e3
+        w.close()
+        rows[str(n)] = {"ms_per_step": round(ms, 4), "Msamples/s": round(n * BLOCK * cfg["ch"] / (ms * 1e-3) / 1e6, 1),
+                        "one_context_ms": round(ms1, 4)}
+    full = rows[str(max(sizes))]["Msamples/s"]
+    for r in rows.values():
+        r["per_sample_rate_vs_8192"] = round(r["Msamples/s"] / full, 4)
+    return rows
+
+
 def histogram_summary(w, cfg_id):
     """What the oracle decided for the distinct frames of every context (Workload.parity)."""
     subs = sum(w.subframe_types.values()) or 1
@@ -766,6 +789,7 @@ def main():
                     help="input signal of the headline loop: ar2 = SURVEY 8(d)'s generator (the contract; LPC order 2 wins "
                          "everywhere), hi = tests/_pcm.py synth_hi (high LPC orders win) -- for profile collections of "
                          "`variants.high_order_input`; the default line reports both")
+    ap.add_argument("--only-batch-sweep", action="store_true", help="print the batch_sweep block alone and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -819,6 +843,9 @@ def main():
 
     from flac_codec_amd.parallel import gather_shard_counters, shard_range
 
+    if args.only_batch_sweep:
+        print(json.dumps({f"config{c}": batch_sweep(torch, c, args, local_rank) for c in (3, 4)}))
+        return
     cfg = CONFIGS[args.config]
     C, BPS, RATE, MAX_LPC = cfg["ch"], cfg["bps"], cfg["rate"], cfg["lpc"]
     strong = args.scaling == "strong"
@@ -950,6 +977,7 @@ def main():
                         # the order-32 configuration on an input that makes the encoder choose orders >= 20
                         others[f"config{cid}"]["high_order_input"] = measure_other_config(torch, cid, args, local_rank, orc,
                                                                                           signal="hi")
+            variants["batch_sweep"] = {f"config{c}": batch_sweep(torch, c, args, local_rank) for c in (3, 4)}
             if CONFIGS[args.config]["lpc"] and args.signal == "ar2":
                 # the headline configuration on an input on which the encoder chooses HIGH LPC orders (SURVEY's generator
                 # makes it choose order 2 everywhere: `value` times a 2-tap FIR)

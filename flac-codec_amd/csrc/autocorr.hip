@@ -23,7 +23,11 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
     const bool private_tiles = kn.ac_private;  // previous kernel (A/B runs)
     if constexpr (STEREO) {
         if (p.inter) {   // interleaved input read in place (the host selects this only with the 4-way split)
-            if (kn.ac_eight_waves && NL == 13)
+            // small batches (<= 1024 frames: at most 64 workgroups for 256 CUs) are a latency problem -- the serial walk
+            // over a frame's samples -- and take the eight-wave split of the lags, whose walk is shorter (512 frames:
+            // 0.0555 -> 0.0441 ms per batch in the four-context loop, profiles/r04_batch_sweep.json); large batches are a
+            // throughput problem and keep four waves (the eight-wave kernel reads the tile twice as often)
+            if ((kn.ac_eight_waves || groups <= 64) && NL == 13)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<13, 8, true, true>), dim3(groups), dim3(512), 0, st, p,
                                    frame0, nframes, n, win);
             else
