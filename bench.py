@@ -65,13 +65,34 @@ HI_SECTIONS = {3: 6, 4: 6, 5: 16}    # resonator sections of the high-order inpu
 def make_pcm(seed, frames, channels, bps, signal="ar2", sections=6):
     """signal "ar2": SURVEY.md 8(d)'s generator (one 2-pole resonator: the encoder answers with LPC order 2);
     "hi": tests/_pcm.py synth_hi, cascaded resonators whose model order changes every 8 frames (orders 8-12 with 6
-    sections, 22-32 with 16) together with the relation between the channels."""
+    sections, 22-32 with 16) together with the relation between the channels.
+    The DISTINCT base frames are generated once per box and configuration and kept under /dev/shm (the ranks of a
+    multi-GPU run all use the same few buffers: whoever comes first writes the file, the others read it)."""
     from _pcm import synth_fast, synth_hi
 
-    if signal == "hi":
-        base = synth_hi(seed, channels, bps, BLOCK * min(DISTINCT, frames), sections=sections)
-    else:
-        base = synth_fast(seed, channels, bps, BLOCK * min(DISTINCT, frames))
+    n = BLOCK * min(DISTINCT, frames)
+    key = f"flacbench_{signal}_{seed}_{channels}_{bps}_{n}_{sections}.npy"
+    shm = os.environ.get("FLAC_BENCH_CACHE", "/dev/shm")
+    path = os.path.join(shm, key) if os.path.isdir(shm) and os.access(shm, os.W_OK) else None
+    base = None
+    if path and os.path.exists(path):
+        try:
+            base = np.load(path)
+            if base.size != n * channels:
+                base = None
+        except Exception:
+            base = None
+    if base is None:
+        base = (synth_hi(seed, channels, bps, n, sections=sections) if signal == "hi"
+                else synth_fast(seed, channels, bps, n))
+        if path:
+            try:   # written under a private name, then renamed: a reader never sees half a file
+                tmp = f"{path}.{os.getpid()}.tmp"
+                with open(tmp, "wb") as fh:
+                    np.save(fh, base)
+                os.replace(tmp, path)
+            except OSError:
+                pass
     reps = (frames + DISTINCT - 1) // DISTINCT
     return np.tile(base, reps)[: frames * BLOCK * channels]
 
@@ -430,8 +451,9 @@ class Workload:
         # context i encodes its own PCM (seed differs); `pcm` given: every context the caller's samples (strong
         # scaling: the rank's range of ONE stream)
         self.signal = signal
-        self.pcm = [pcm if pcm is not None else make_pcm(1000 + 16 * cfg_id + seed_rank + 101 * i, frames, self.C, self.BPS,
-                                                         signal, HI_SECTIONS.get(cfg_id, 6))
+        # (the same `contexts` buffers on every rank, rotated by the rank: one generation per box, /dev/shm above)
+        self.pcm = [pcm if pcm is not None else make_pcm(1000 + 16 * cfg_id + 101 * ((i + seed_rank) % contexts), frames, self.C,
+                                                         self.BPS, signal, HI_SECTIONS.get(cfg_id, 6))
                     for i in range(contexts)]
         self.d_pcm = [torch.from_numpy(p).cuda() for p in self.pcm]
         self.ans = [GpuAnalyzer(BLOCK, self.PO, self.LPC, True, True, 2, 0.5, self.BPS, self.C, max_frames=frames,

@@ -50,25 +50,53 @@ def all_gather_counters(local, dist=None, device=None):
     return [[int(v) for v in t.tolist()] for t in out]
 
 
-def merge_counters(per_rank):
+def merge_counters(per_rank, dist=None):
     """Stream-level bookkeeping from the per-shard records: byte offset of every shard's first
-    frame (exclusive prefix sum), totals and STREAMINFO min/max frame size."""
+    frame (exclusive prefix sum), totals and STREAMINFO min/max frame size (ranks without frames -- more ranks than
+    frames -- take no part in min / max).  `ranks_seen` is the length of the all-gather's result and `backend` the
+    collective backend that produced it: a scaling record carrying them proves that N ranks met over RCCL."""
     offsets, acc = [], 0
     for c in per_rank:
         offsets.append(acc)
         acc += c[1]
+    busy = [c for c in per_rank if c[0]]
+    backend = dist.get_backend() if dist is not None and dist.is_initialized() else None
     return {
         "shard_byte_offsets": offsets,
         "total_frames": sum(c[0] for c in per_rank),
         "total_bytes": acc,
-        "min_frame": min(c[2] for c in per_rank),
-        "max_frame": max(c[3] for c in per_rank),
+        "min_frame": min(c[2] for c in busy) if busy else 0,
+        "max_frame": max(c[3] for c in busy) if busy else 0,
+        "frames_per_rank": [c[0] for c in per_rank],
+        "ranks_seen": len(per_rank),
+        "backend": backend,
     }
 
 
 def gather_shard_counters(analyzer, n_frames, dist=None):
     per_rank = all_gather_counters(local_counters(analyzer, n_frames), dist)
-    return merge_counters(per_rank)
+    return merge_counters(per_rank, dist)
+
+
+def gather_exact(payload, lengths, dist, dtype):
+    """Rank 0 receives every rank's `payload` (a 1-D tensor of lengths[rank] elements) at its EXACT length -- point to
+    point, rank by rank: no padding to the longest shard (a gather of max-sized buffers moved world x max bytes and
+    allocated as much on the owner).  Returns the list of tensors on rank 0, None elsewhere."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = payload.device
+    if rank != 0:
+        if lengths[rank]:
+            dist.send(payload, dst=0)
+        return None
+    out = [payload]
+    for r in range(1, world):
+        buf = torch.empty(lengths[r], dtype=dtype, device=dev)
+        if lengths[r]:
+            dist.recv(buf, src=r)
+        out.append(buf)
+    return out
 
 
 def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, dist=None, device=-1,
@@ -142,28 +170,22 @@ def finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sampl
     B, C = co.block_size, channels
     local = [len(sizes), len(mine), min(sizes) if sizes else 0, max(sizes) if sizes else 0]
     per_rank = all_gather_counters(local, dist)
-    merged = merge_counters([c for c in per_rank if c[0]] or per_rank)
+    merged = merge_counters(per_rank, dist)
     if world > 1:
         import torch
 
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        max_frames = max(c[0] for c in per_rank)
-        max_bytes = max(c[1] for c in per_rank)
-        tsz = torch.zeros(max_frames, dtype=torch.int64, device=dev)
-        tsz[: len(sizes)] = torch.tensor(sizes, dtype=torch.int64)
-        tby = torch.zeros(max_bytes, dtype=torch.uint8, device=dev)
-        if mine:
-            tby[: len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
-        gsz = [torch.zeros_like(tsz) for _ in range(world)] if rank == 0 else None
-        gby = [torch.zeros_like(tby) for _ in range(world)] if rank == 0 else None
-        dist.gather(tsz, gsz, dst=0)
-        dist.gather(tby, gby, dst=0)
+        tsz = torch.tensor(sizes, dtype=torch.int32, device=dev) if sizes else torch.empty(0, dtype=torch.int32, device=dev)
+        tby = (torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(dev) if mine
+               else torch.empty(0, dtype=torch.uint8, device=dev))
+        gsz = gather_exact(tsz, [c[0] for c in per_rank], dist, torch.int32)
+        gby = gather_exact(tby, [c[1] for c in per_rank], dist, torch.uint8)
         if rank != 0:
             return None
         all_sizes, body = [], []
-        for r, c in enumerate(per_rank):
-            all_sizes.extend(int(v) for v in gsz[r][: c[0]].tolist())
-            body.append(bytes(gby[r][: c[1]].cpu().numpy().tobytes()))
+        for r in range(world):
+            all_sizes.extend(int(v) for v in gsz[r].tolist())
+            body.append(gby[r].cpu().numpy().tobytes())
         body = b"".join(body)
     else:
         all_sizes, body = list(sizes), mine
