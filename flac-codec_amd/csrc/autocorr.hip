@@ -9,10 +9,12 @@
 
 namespace {
 #include "kernels/common.inc"
+#include "kernels/lpc.inc"        // lpc_candidate: the Levinson tail of the DIRECT k_autocorr4 instantiations
 #include "kernels/autocorr.inc"
 
+// returns true when the launched kernel also ran K4 (Levinson, order choice, quantisation, candidate info) in its tail
 template <int NL, bool STEREO>
-void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
+bool launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                       const double *win, hipStream_t st) {
     const uint32_t groups = (nframes * p.ncand + 63) / 64;
     // 4 waves per 64 candidates (lags split 4 ways) by default: the f64 stream needs two waves per
@@ -27,27 +29,36 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
             // over a frame's samples -- and take the eight-wave split of the lags, whose walk is shorter (512 frames:
             // 0.0555 -> 0.0441 ms per batch in the four-context loop, profiles/r04_batch_sweep.json); large batches are a
             // throughput problem and keep four waves (the eight-wave kernel reads the tile twice as often)
-            if ((kn.ac_eight_waves || groups <= 64) && NL == 13)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<13, 8, true, true>), dim3(groups), dim3(512), 0, st, p,
-                                   frame0, nframes, n, win);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
-                                   frame0, nframes, n, win);
-            return;
+            const bool fuse = !kn.no_lpc_fuse;
+            if ((kn.ac_eight_waves || groups <= 64) && NL == 13) {
+                if (fuse) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<13, 8, true, true, 0, true>), dim3(groups), dim3(512), 0, st, p,
+                                             frame0, nframes, n, win);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<13, 8, true, true>), dim3(groups), dim3(512), 0, st, p,
+                                        frame0, nframes, n, win);
+            } else {
+                if (fuse) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true, 0, true>), dim3(groups), dim3(256), 0, st, p,
+                                             frame0, nframes, n, win);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, true, true>), dim3(groups), dim3(256), 0, st, p,
+                                        frame0, nframes, n, win);
+            }
+            return fuse;
         }
     }
     if constexpr (!STEREO) {
         if (p.split_src) {   // interleaved independent channels: the producers split them on the way (no K0 pass)
-            if (p.channels == 8)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, 8>), dim3(groups), dim3(256), 0, st, p,
-                                   frame0, nframes, n, win);
-            else if (p.channels == 4)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, 4>), dim3(groups), dim3(256), 0, st, p,
-                                   frame0, nframes, n, win);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true>), dim3(groups), dim3(256), 0, st, p,
-                                   frame0, nframes, n, win);
-            return;
+            const bool fuse = !kn.no_lpc_fuse;
+#define AC4_SPLIT(C)                                                                                                      \
+    do {                                                                                                                  \
+        if (fuse) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, C, true>), dim3(groups), dim3(256), 0, st, p, \
+                                     frame0, nframes, n, win);                                                            \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, false, true, C>), dim3(groups), dim3(256), 0, st, p,   \
+                                frame0, nframes, n, win);                                                                 \
+    } while (0)
+            if (p.channels == 8) AC4_SPLIT(8);
+            else if (p.channels == 4) AC4_SPLIT(4);
+            else AC4_SPLIT(0);
+#undef AC4_SPLIT
+            return fuse;
         }
     }
     if (!private_tiles) {  // shared conversion through LDS
@@ -57,7 +68,7 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
                                frame0, nframes, n, win);
-        return;
+        return false;
     }
     if (p.ac_split == 2)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 2, STEREO>), dim3(groups), dim3(128), 0, st, p,
@@ -65,20 +76,23 @@ void launch_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3<NL, 4, STEREO>), dim3(groups), dim3(256), 0, st, p,
                            frame0, nframes, n, win);
+    return false;
 }
 template <bool STEREO>
-void launch_autocorr3_nl(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
+bool launch_autocorr3_nl(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
                          hipStream_t st) {
     const uint32_t nl = p.max_lpc_order + 1;
-    if (nl <= 5) launch_autocorr3<5, STEREO>(p, kn, frame0, nframes, n, win, st);
-    else if (nl <= 9) launch_autocorr3<9, STEREO>(p, kn, frame0, nframes, n, win, st);
-    else if (nl <= 13) launch_autocorr3<13, STEREO>(p, kn, frame0, nframes, n, win, st);
-    else launch_autocorr3<17, STEREO>(p, kn, frame0, nframes, n, win, st);
+    if (nl <= 5) return launch_autocorr3<5, STEREO>(p, kn, frame0, nframes, n, win, st);
+    if (nl <= 9) return launch_autocorr3<9, STEREO>(p, kn, frame0, nframes, n, win, st);
+    if (nl <= 13) return launch_autocorr3<13, STEREO>(p, kn, frame0, nframes, n, win, st);
+    return launch_autocorr3<17, STEREO>(p, kn, frame0, nframes, n, win, st);
 }
 // frame length a multiple of 32, order <= 16, and either stereo L/R/M/S candidates of <= 24-bit
 // samples (mid/side formed with one v_mad_i32_i24) or independent channels of any width
+// *fused: K4 ran in the kernel's tail (launch_autocorr3)
 bool try_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n, const double *win,
-                   hipStream_t st) {
+                   hipStream_t st, bool *fused) {
+    *fused = false;
     if (n < 32 || n % 32 != 0 || kn.no_ac3) return false;
     const bool stereo = p.stereo4 && p.ncand == 4 && p.channels == 2 && p.bps <= 24;
     const bool indep = !p.stereo4 && p.ncand == p.channels;
@@ -106,8 +120,8 @@ bool try_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t n
         }
         return true;
     }
-    if (stereo) launch_autocorr3_nl<true>(p, kn, frame0, nframes, n, win, st);
-    else launch_autocorr3_nl<false>(p, kn, frame0, nframes, n, win, st);
+    if (stereo) *fused = launch_autocorr3_nl<true>(p, kn, frame0, nframes, n, win, st);
+    else *fused = launch_autocorr3_nl<false>(p, kn, frame0, nframes, n, win, st);
     return true;
 }
 
@@ -121,7 +135,7 @@ void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_
 }  // namespace
 
 namespace flacgpu_k {
-void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
+bool dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st) {
     // EXPERIMENT switch (bench.py --experiment mfma_autocorr): the re-associating f64-MFMA kernel in
     // place of the exact one, to measure what a whole step costs with the autocorrelation off the
@@ -130,9 +144,10 @@ void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t fr
     if (mfma && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 && frame0 == 0 && nframes == p.n_frames &&
         n == p.block_size) {
         hipLaunchKernelGGL(k_autocorr_mfma, dim3((nframes * p.ncand + 3) / 4), dim3(WG), 0, st, p, n, win, p.ac);
-        return;
+        return false;
     }
-    if (try_autocorr3(p, kn, frame0, nframes, n, win, st)) return;
+    bool fused = false;
+    if (try_autocorr3(p, kn, frame0, nframes, n, win, st, &fused)) return fused;
     switch (H) {
     case 4: launch_autocorr<4>(p, frame0, nframes, n, win, st); break;
     case 8: launch_autocorr<8>(p, frame0, nframes, n, win, st); break;
@@ -144,6 +159,7 @@ void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t fr
     case 32: launch_autocorr<32>(p, frame0, nframes, n, win, st); break;
     default: launch_autocorr<36>(p, frame0, nframes, n, win, st); break;
     }
+    return false;
 }
 void launch_autocorr_mfma(const Params &p, uint32_t blocks, uint32_t n, const double *win, double *ac,
                           hipStream_t st) {

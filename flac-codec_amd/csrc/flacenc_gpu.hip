@@ -66,6 +66,7 @@ Knobs read_knobs() {
     k.no_cand_pair = on("FLACGPU_NO_CAND_PAIR");
     k.force_fir_check = on("FLACGPU_FIR_CHECK");
     k.no_sub64 = on("FLACGPU_NO_SUB64");
+    k.no_lpc_fuse = on("FLACGPU_NO_LPC_FUSE");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
@@ -796,10 +797,13 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         const uint32_t H = ((p.max_lpc_order + 1) + 3u) & ~3u;
         begin(3);
         const uint32_t full = (last_len == B) ? n_frames : n_frames - 1;
-        if (full) dispatch_autocorr(H, p, c->knobs, 0, full, B, c->d_window_full, st);
-        if (full != n_frames) dispatch_autocorr(H, p, c->knobs, full, 1, last_len, c->d_window_last, st);
-        begin(4);
-        launch_lpc(p, c->knobs, (ncb + 63) / 64, st);
+        bool k4_done = false;   // the direct autocorrelation kernels run K4 in their tail (whole blocks only: one launch)
+        if (full) k4_done = dispatch_autocorr(H, p, c->knobs, 0, full, B, c->d_window_full, st);
+        if (full != n_frames) k4_done = dispatch_autocorr(H, p, c->knobs, full, 1, last_len, c->d_window_last, st) && k4_done;
+        if (!k4_done || full != n_frames) {
+            begin(4);
+            launch_lpc(p, c->knobs, (ncb + 63) / 64, st);
+        }
         if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         if (pg.fcount) {
             begin(5);
@@ -1164,8 +1168,8 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         if (c->stereo4 && !p.exhaustive) hipLaunchKernelGGL(k_stereo_stats_t<false>, dim3(r.fcount), dim3(WG), 0, st, r);
         hipLaunchKernelGGL(k_candinfo, dim3((ncb + WG - 1) / WG), dim3(WG), 0, st, r, c->d_orbits, (const unsigned long long *)nullptr);
         if (lpc) {
-            dispatch_autocorr(H, r, c->knobs, r.f0, r.fcount, B, c->d_window_full, st);
-            launch_lpc(r, c->knobs, (ncb + 63) / 64, st);
+            if (!dispatch_autocorr(H, r, c->knobs, r.f0, r.fcount, B, c->d_window_full, st))
+                launch_lpc(r, c->knobs, (ncb + 63) / 64, st);
         }
         if (!launch_cand64(r, c->knobs, B, (ncb + 3) / 4, st)) hipLaunchKernelGGL(k_decide, dim3(r.fcount), dim3(64), 0, st, r);
         // frame assembly of this range; the second range's offsets continue from the first's

@@ -162,6 +162,7 @@ struct Knobs {
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
+         no_lpc_fuse = false,      // A/B: K4 as a launch of its own behind the direct autocorrelation (FLACGPU_NO_LPC_FUSE)
          no_sub64 = false,         // A/B: frames of 3..8 channels assembled by one workgroup per FRAME (k_frame64) (FLACGPU_NO_SUB64)
          no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
     bool upload_by_kernel = false;      // A/B: the asynchronous host path reads the caller's pinned PCM with kernel loads (FLACGPU_UPLOAD_KERNEL)
@@ -189,7 +190,8 @@ bool launch_cand64_direct_short(const Params &p, const Knobs &kn, uint32_t B, ui
 // cand_split.hip: eight waves per stereo frame ({L, R, mid, side} x {FIXED, LPC}); false: shape not served
 bool launch_cand64_split(const Params &p, uint32_t B, uint32_t frames, uint32_t grid_cap, hipStream_t st);
 // autocorr.hip
-void dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
+// returns true when the kernel also ran K4 in its tail (the DIRECT k_autocorr4 instantiations): no launch_lpc then
+bool dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st);
 void launch_autocorr_mfma(const Params &p, uint32_t blocks, uint32_t n, const double *win, double *ac,
                           hipStream_t st);
