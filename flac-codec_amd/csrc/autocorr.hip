@@ -102,8 +102,17 @@ bool try_autocorr3(const Params &p, const Knobs &kn, uint32_t frame0, uint32_t n
         const uint32_t groups = (nframes * p.ncand + 63) / 64;
         const bool private_deep = kn.ac_private;
         if (stereo && p.inter) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true, true>), dim3(groups), dim3(256), 0, st, p, frame0,
-                               nframes, n, win);
+            // (K4 in the tail of the deep kernel: measured and left off -- 228 instead of 153 VGPRs leave no room for another
+            // kernel's wave beside two of these, and the four-context step of config 5 goes 0.566 -> 0.588 ms;
+            // FLACGPU_LPC_FUSE_DEEP=1 for A/B runs, profiles/r04_autocorr_lpc_fuse.json)
+            if (kn.lpc_fuse_deep && !kn.no_lpc_fuse) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true, true, true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                                   nframes, n, win);
+                *fused = true;
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr4_deep<true, true>), dim3(groups), dim3(256), 0, st, p, frame0,
+                                   nframes, n, win);
+            }
         } else if (private_deep) {
             if (stereo)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_autocorr3_deep<true>), dim3(groups), dim3(256), 0, st, p, frame0,

@@ -68,6 +68,7 @@ Knobs read_knobs() {
     k.no_sub64 = on("FLACGPU_NO_SUB64");
     k.no_lpc_fuse = on("FLACGPU_NO_LPC_FUSE");
     k.cand_gather = on("FLACGPU_CAND_GATHER");
+    k.lpc_fuse_deep = on("FLACGPU_LPC_FUSE_DEEP");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");

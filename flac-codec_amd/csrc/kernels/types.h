@@ -162,6 +162,7 @@ struct Knobs {
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
+         lpc_fuse_deep = false,    // A/B: K4 in the tail of k_autocorr4_deep as well (FLACGPU_LPC_FUSE_DEEP; measured slower)
          cand_gather = false,      // EXPERIMENT: k_cand64 gathers its channel out of the interleaved batch (FLACGPU_CAND_GATHER)
          no_lpc_fuse = false,      // A/B: K4 as a launch of its own behind the direct autocorrelation (FLACGPU_NO_LPC_FUSE)
          no_sub64 = false,         // A/B: frames of 3..8 channels assembled by one workgroup per FRAME (k_frame64) (FLACGPU_NO_SUB64)
