@@ -180,41 +180,56 @@ def floor(kernel, blocks, cost, dyn_insts, units=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm-dir", default=os.path.join(ROOT, "flac-codec_amd", "csrc"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_issue_floor.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_issue_floor.json"))
+    ap.add_argument("--tag", default="r04", help="round tag of the counter collections (profiles/<tag>_b_valu.json, <tag>_cfg2_valu.json ...)")
     ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r03_issue_rate_ubench.json"))
     a = ap.parse_args()
     cost = costs(a.ubench)
     prof = os.path.join(ROOT, "profiles")
 
+    build_ids = set()
+
     def dyn(tag, kernel):
         v = json.load(open(os.path.join(prof, f"{tag}_valu.json")))
+        build_ids.add(v.get("_build_id"))
         return v[kernel]["SQ_INSTS_VALU"]
 
     A = lambda f: os.path.join(a.asm_dir, f)   # noqa: E731
     out = {"costs_ns_per_wave_inst_per_simd_at_4_waves": cost,
            "method": __doc__.split("usage:")[0].strip()}
+    T = a.tag
     # config 3: the bench signal takes LPC order 2 (2 taps) and fixed order 2
     cd = blocks_of(A("cand_direct.gfx950.s"), "k_cand64pILi64ELi16ELb1ELb1ELb0")
-    ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1")
+    ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1ELi0ELb1")
     fr = blocks_of(A("frame64_d.gfx950.s"), "k_frame64ILi128ELi64ELi16ELb1")
     out["config3"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn("r03_f", "k_cand64p"), 32768),
-        "k_autocorr": floor("k_autocorr4<13,4,true,true>", pick_loops(ac), cost, dyn("r03_f", "k_autocorr4")),
-        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn("r03_f", "k_frame64")),
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn(f"{T}_b", "k_cand64p"), 32768),
+        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(f"{T}_b", "k_autocorr4")),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_b", "k_frame64")),
+    }
+    # config 3 on the high-order input: orders 8..12 win (10 taps as the representative instantiation)
+    out["config3hi"] = {
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 10, 2), cost, dyn(f"{T}_hi", "k_cand64p"), 32768),
+        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(f"{T}_hi", "k_autocorr4")),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_hi", "k_frame64")),
     }
     # config 2: no LPC (SELF variant)
     c2 = blocks_of(A("cand_direct.gfx950.s"), "k_cand64pILi64ELi16ELb1ELb1ELb1")
     out["config2"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true,SELF>", pick_cand(c2, 99, 2), cost, dyn("r03_cfg2", "k_cand64p"), 32768),
-        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn("r03_cfg2", "k_frame64")),
+        "k_cand64": floor("k_cand64p<64,16,true,true,SELF>", pick_cand(c2, 99, 2), cost, dyn(f"{T}_cfg2", "k_cand64p"), 32768),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_cfg2", "k_frame64")),
     }
-    # config 5: order 32
+    # config 5: order 32 (the bench signal: 2 taps; the high-order input: 28 taps as the representative instantiation)
     c5 = blocks_of(A("cand_direct.gfx950.s"), "k_cand64pILi64ELi32ELb1ELb1ELb0")
     out["config5"] = {
-        "k_cand64": floor("k_cand64p<64,32,true,true>", pick_cand(c5, 32, 2), cost, dyn("r03_cfg5", "k_cand64p"), 32768),
+        "k_cand64": floor("k_cand64p<64,32,true,true>", pick_cand(c5, 2, 2), cost, dyn(f"{T}_cfg5", "k_cand64p"), 32768),
     }
+    out["config5hi"] = {
+        "k_cand64": floor("k_cand64p<64,32,true,true>", pick_cand(c5, 28, 2), cost, dyn(f"{T}_cfg5hi", "k_cand64p"), 32768),
+    }
+    out["_build_id"] = build_ids.pop() if len(build_ids) == 1 else None
     json.dump(out, open(a.out, "w"), indent=1)
-    for cfg in ("config3", "config2", "config5"):
+    for cfg in ("config3", "config3hi", "config2", "config5", "config5hi"):
         for k, v in out[cfg].items():
             print(cfg, k, v["kernel_symbol"], "path", v["static_valu_insts_of_path"], "avg ns", v["avg_ns_per_wave_inst_per_simd"],
                   "dyn", f"{v['dynamic_valu_wave_insts'] / 1e6:.1f}M", "attainable_ms", v["attainable_ms"])
