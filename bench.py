@@ -682,6 +682,8 @@ def profile_figures(cfg_id, dom, dom_ms, signal="ar2"):
     try:
         name, t = newest("traffic")
         k2 = key if key in t else (key[:-1] if key.endswith("p") and key[:-1] in t else None)
+        if k2 is None and key == "k_frame64" and "k_sub64" in t:
+            k2 = "k_sub64"     # 5..8 channels: one workgroup per subframe assembles the frames
         if k2:
             traffic = t[k2]["hbm_bytes"]
             traffic_src = {"source": "profiles/" + name, "kernel": k2, "build_id": t.get("_build_id"),
@@ -692,6 +694,8 @@ def profile_figures(cfg_id, dom, dom_ms, signal="ar2"):
     try:
         name, vt = newest("valu")
         k2 = key if key in vt else (key[:-1] if key.endswith("p") and key[:-1] in vt else None)
+        if k2 is None and key == "k_frame64" and "k_sub64" in vt:
+            k2 = "k_sub64"
         if k2 and vt[k2].get("SQ_INSTS_VALU"):
             insts = vt[k2]["SQ_INSTS_VALU"]
             valu = {"wave_insts_per_launch": insts, "source": "profiles/" + name, "build_id": vt.get("_build_id"),
