@@ -129,3 +129,37 @@ def test_c_recipe_matches_oracle(tmp_path, width):
                 h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert (size, n_frames) == (total, batches * fpb)
     assert digest == h
+
+
+def test_eight_channels_through_the_pipeline():
+    """5..8 channels are assembled by k_sub64 (one workgroup per subframe), whose plain stores write the frames into the
+    slot's pinned host buffer like k_frame64's do: the rotation must still give the synchronous call's bytes and the oracle's."""
+    from flac_codec_amd.gpu import GpuAnalyzer, PinnedBuffer, Pipeline
+
+    ch, bps, fpb, depth = 8, 24, 6, 2
+    pcm = np.ascontiguousarray(synth_hi(77, ch, bps, B * fpb * 3, sections=6))
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=fpb)
+    pipe = Pipeline(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=fpb, depth=depth)
+    bufs = [PinnedBuffer(fpb * B * ch * 4) for _ in range(depth)]
+    got, expect = [], []
+    for b in range(3):
+        if pipe.in_flight() == depth:
+            got.append(pipe.retire())
+        chunk = pcm[b * fpb * B * ch: (b + 1) * fpb * B * ch]
+        bufs[b % depth].array[:] = chunk.view(np.uint8)
+        assert pipe.submit(bufs[b % depth].address, 4, fpb, B, b * fpb, 192000)
+        expect.append(an.encode_frames(chunk, fpb, B, b * fpb, 192000))
+    while pipe.in_flight():
+        got.append(pipe.retire())
+    assert [g[0] for g in got] == [e[0] for e in expect] and [g[1] for g in got] == [e[1] for e in expect]
+    oopts = orc_options_for(B, 6, 12, True, True)
+    data = b"".join(g[0] for g in got)
+    pos = 0
+    for f, planar in enumerate(planar_frames(pcm, ch, B)):
+        rc, fb, _ = orc.encode_frame(oopts, 192000, bps, planar, frame_number=f)
+        assert rc == 0 and data[pos:pos + len(fb)] == fb, f
+        pos += len(fb)
+    pipe.close()
+    an.close()
+    for b in bufs:
+        b.close()
