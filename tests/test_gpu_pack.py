@@ -121,6 +121,8 @@ def test_fast_preset_and_sines():
     (2, 16, 5, 0, True),      # FIXED only
     (1, 24, 6, 12, True),
     (3, 20, 6, 16, True),
+    (8, 24, 6, 12, True),     # 5..8 channels: k_sub64 (one workgroup per subframe) on both ranges
+    (6, 16, 5, 8, True),
 ])
 def test_two_range_pipeline_matches_serial(channels, bps, max_po, max_lpc, exhaustive):
     """flacgpu_encode_device with FLACGPU_TUNE_TWO_RANGES cuts big batches of 4096-sample frames into
