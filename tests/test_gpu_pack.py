@@ -235,3 +235,29 @@ def test_pinned_host_buffers_give_the_same_frames():
     got, off, times = an.encode_frames_pinned(pcm, 7, 1000, 9, 48000, repeat=3)
     an.close()
     assert got == want and off == want_off and len(times) == 3
+
+
+@pytest.mark.parametrize("channels", [2, 4, 8])
+def test_pack_plans_of_wave_block_frames(channels):
+    """flacgpu_pack_plans with the decisions an analysis made (fetched to the host and handed back): frames of 4096 samples take
+    the wave assembly kernels -- k_frame64, or k_sub64 + k_sub_finish for 8 channels -- and must come out as the bytes of
+    the ordinary path, with a short last frame (generic packer) behind them."""
+    import ctypes as C
+
+    from flac_codec_amd import _lib
+    from flac_codec_amd._lib import FramePlan, SubframePlan
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    n, block, last = 9, 4096, 1500
+    pcm = np.ascontiguousarray(synth_fast(640 + channels, channels, 24, (n - 1) * block + last))
+    an = GpuAnalyzer(block, 6, 12, True, True, 2, 0.5, 24, channels, max_frames=n)
+    want, want_off = an.encode_frames(pcm, n, last, 41, 96000)
+    plans, subs, _ = an.analyze(pcm, n, last)
+    L = _lib.lib()
+    L.flacgpu_pack_plans.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(FramePlan),
+                                     C.POINTER(SubframePlan), C.c_uint64, C.c_uint32]
+    rc = L.flacgpu_pack_plans(an._h, pcm.ctypes.data_as(C.POINTER(C.c_int32)), n, last, plans, subs, 41, 96000)
+    assert rc == 0, L.flacgpu_last_error()
+    got, got_off = an.fetch_frames(n)
+    assert got_off == want_off and got == want
+    an.close()
