@@ -11,7 +11,7 @@ import pytest
 
 import _oracle as orc
 from _compare import frames_the_reference_cannot_decode, orc_options_for, planar_frames
-from _pcm import synth_fast
+from _pcm import synth_fast, synth_hi
 
 pytestmark = pytest.mark.gpu
 
@@ -45,9 +45,8 @@ def make_signal(rng, kind, channels, bps, n):
     raise ValueError(kind)
 
 
-def one_case(seed):
-    from flac_codec_amd.gpu import GpuAnalyzer
-
+def case_of(seed):
+    """The parameters and the PCM of one seeded case (tools/soak/diag_case.py replays a case through this)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     block = int(rng.choice([1024, 1152, 2048, 2304, 4096, 4096, 4096, 192, 576, 1000, 4608, 16, 333, 8192]))
     channels = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 8]))
@@ -69,11 +68,31 @@ def one_case(seed):
     if kind == "shifted" and bps < 12:
         kind = "synth"
     n = (n_frames - 1) * block + last
-    pcm = make_signal(rng, kind, channels, bps, n)
+    # r04: a third of the "synth" cases become resonant AR(k) signals (tests/_pcm.py synth_hi), on which the encoder
+    # chooses high LPC orders.  Decided by a generator of its own: the draws of `rng` -- and with them every seed the
+    # earlier rounds pinned (306266 below) -- stay what they were.
+    rng2 = np.random.Generator(np.random.PCG64(seed ^ 0x5EED0004))
+    if kind == "synth" and bps >= 12 and rng2.integers(3) == 0:
+        kind = "resonant"
+        orders = [int(v) for v in rng2.integers(1, 33, size=4)]
+        pcm = synth_hi(int(rng2.integers(1 << 30)), channels, bps, n, segment=max(16, block), orders=orders)
+    else:
+        pcm = make_signal(rng, kind, channels, bps, n)
     rate = int(rng.choice([8000, 44100, 48000, 96000, 192000, 12345]))
     first = int(rng.choice([0, 127, 128, 70000, (1 << 31) - 8]))
     desc = (f"seed {seed}: block {block} ch {channels} bps {bps} lpc {max_lpc} po {max_po} ms {mid_side} "
             f"ex {exhaustive} win {window} frames {n_frames} last {last} {kind} rate {rate} first {first}")
+    return dict(block=block, channels=channels, bps=bps, max_lpc=max_lpc, max_po=max_po, mid_side=mid_side,
+                exhaustive=exhaustive, window=window, n_frames=n_frames, last=last, kind=kind, rate=rate, first=first, desc=desc), pcm
+
+
+def one_case(seed):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    c, pcm = case_of(seed)
+    block, channels, bps, max_lpc, max_po = c["block"], c["channels"], c["bps"], c["max_lpc"], c["max_po"]
+    mid_side, exhaustive, window, n_frames, last = c["mid_side"], c["exhaustive"], c["window"], c["n_frames"], c["last"]
+    rate, first, desc = c["rate"], c["first"], c["desc"]
     an = GpuAnalyzer(block, max_po, max_lpc, mid_side, exhaustive, window[0], window[1], bps, channels,
                      max_frames=n_frames)
     try:
@@ -123,3 +142,20 @@ def test_partition_corner_of_very_short_frames():
     assert frames_the_reference_cannot_decode(subs, 1, 2, 4608, 4) == {0}
     assert (res.frames, res.bad_structure, res.bad_crc16) == (1, 1, 0)
     one_case(306266)   # the seed of the sweep that met it (three frames, the last one this one)
+
+
+def test_rice_codes_of_exactly_33_bits_behind_an_empty_bit_register():
+    """Seed 1264 of the r04 sweep (8 channels, 32-bit samples, a resonant signal: Rice parameters 27 / 28 with quotients
+    of 4 / 5, i.e. codes of exactly 33 bits): the device decoder's one-refill route read the last bit of such a code -- the
+    sign of the residual -- as zero when the code before it had emptied the bit register.  The encoder's bytes were the
+    oracle's all along; the verifier flagged sound frames and the stand-alone decoder would have returned a wrong sample."""
+    from flac_codec_amd.gpu import decode_stream
+
+    one_case(1264)
+    c, pcm = case_of(1264)
+    ch0 = np.ascontiguousarray(pcm.reshape(-1, c["channels"])[3 * c["block"]:, 0])     # the subframe the diagnosis used
+    oo = orc_options_for(c["block"], c["max_po"], c["max_lpc"], c["mid_side"], c["exhaustive"], c["window"][0], c["window"][1])
+    rc, flac, _ = orc.encode_stream(oo, c["rate"], 32, 1, ch0, total_known=True)
+    assert rc == 0
+    out, info = decode_stream(flac)
+    assert info.bad_frames == 0 and info.bad_crc16 == 0 and info.md5_status == 1 and np.array_equal(out, ch0)
