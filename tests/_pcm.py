@@ -183,3 +183,18 @@ def synth_hi(seed, channels, bps, n, sections=6, segment=4096 * 8, modes=STEREO_
     for c in range(channels):
         out[c::channels] = chans[c].astype(np.int32)
     return out
+
+
+def synth_burst(seed, channels, bps, n, block, burst=40, order=32):
+    """A resonant AR(order) signal (synth_hi) whose blocks END in `burst` samples of full-scale noise.  The Tukey window
+    hides the burst from the autocorrelation, so the predictor is the resonant one -- large quantised coefficients at a
+    small shift --, and over the burst it predicts garbage: residuals of 2^28 .. 2^30 and, now and then, a prediction
+    outside the i32 range (ResidualOverflow, encode.rs:3190-3197).  The input of the overflow-handling tests."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xB0057))
+    x = synth_hi(seed, channels, bps, n, segment=block, orders=[order]).reshape(-1, channels).copy()
+    full = 1 << (bps - 1)
+    for f0 in range(0, n, block):
+        b = min(n, f0 + block)
+        a = max(f0, b - burst)
+        x[a:b] = rng.integers(-full, full, size=(b - a, channels), dtype=np.int64).astype(np.int32)
+    return x.reshape(-1)

@@ -11,7 +11,7 @@ import pytest
 
 import _oracle as orc
 from _compare import frames_the_reference_cannot_decode, orc_options_for, planar_frames
-from _pcm import synth_fast, synth_hi
+from _pcm import synth_burst, synth_fast, synth_hi
 
 pytestmark = pytest.mark.gpu
 
@@ -75,7 +75,12 @@ def case_of(seed):
     if kind == "synth" and bps >= 12 and rng2.integers(3) == 0:
         kind = "resonant"
         orders = [int(v) for v in rng2.integers(1, 33, size=4)]
-        pcm = synth_hi(int(rng2.integers(1 << 30)), channels, bps, n, segment=max(16, block), orders=orders)
+        hseed = int(rng2.integers(1 << 30))
+        if rng2.integers(4) == 0 and block >= 256:   # ... a quarter of them with blocks that end in full-scale noise
+            kind = "burst"                           # (drawn after the signal's seed: the resonant cases stay what they were)
+            pcm = synth_burst(hseed, channels, bps, n, block, burst=int(rng2.integers(4, 120)), order=orders[0])
+        else:
+            pcm = synth_hi(hseed, channels, bps, n, segment=max(16, block), orders=orders)
     else:
         pcm = make_signal(rng, kind, channels, bps, n)
     rate = int(rng.choice([8000, 44100, 48000, 96000, 192000, 12345]))

@@ -110,3 +110,36 @@ def test_fir_recheck_path(monkeypatch):
     assert low == expect
     always, st = encode({"FLACGPU_FIR_CHECK": "1"})
     assert always == expect and st.fir_recheck == 0
+
+
+@pytest.mark.parametrize("bps,max_lpc,order,burst", [(24, 32, 32, 40), (24, 32, 32, 8), (24, 12, 12, 60), (16, 16, 16, 100)])
+def test_bursts_that_make_the_predictor_run_wild(monkeypatch, bps, max_lpc, order, burst):
+    """Blocks that end in full-scale noise behind a resonant signal (tests/_pcm.py synth_burst): the LPC residual reaches
+    2^28 .. 2^30 over the burst, so the first analysis cannot rule a ResidualOverflow out from the folded residual for
+    some candidates (flacgpu_stats.fir_recheck > 0 at order 32) and the host has the candidate stage run again with the
+    exact test -- on ordinary input, no test knob.  Bytes: the oracle's, and the always-testing build's."""
+    from _pcm import synth_burst
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    B, n = 4096, 10
+    pcm = synth_burst(7 + burst, 2, bps, B * n, B, burst=burst, order=order)
+    oopts = orc_options_for(B, 6, max_lpc, True, True)
+    expect = [orc.encode_frame(oopts, 48000, bps, planar, frame_number=f)[1] for f, planar in enumerate(planar_frames(pcm, 2, B))]
+    stats = {}
+    for env in ({}, {"FLACGPU_FIR_CHECK": "1"}, {"FLACGPU_NO_DIRECT": "1"}):
+        for k in ("FLACGPU_FIR_CHECK", "FLACGPU_NO_DIRECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        an = GpuAnalyzer(B, 6, max_lpc, True, True, 2, 0.5, bps, 2, max_frames=n)
+        data, off = an.encode_frames(pcm, n, B, 0, 48000)
+        stats[tuple(env)] = an.stats()
+        for f in range(n):
+            assert data[off[f]:off[f + 1]] == expect[f], (env, f)
+        res, _ = an.verify_device(48000, 0)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+        an.close()
+    st = stats[()]
+    assert st.fir_rechecked == st.fir_recheck
+    if (bps, max_lpc, burst) == (24, 32, 40):
+        assert st.fir_recheck > 0, "this input is meant to reach the re-run"
