@@ -81,6 +81,26 @@ def case_of(seed):
             pcm = synth_burst(hseed, channels, bps, n, block, burst=int(rng2.integers(4, 120)), order=orders[0])
         else:
             pcm = synth_hi(hseed, channels, bps, n, segment=max(16, block), orders=orders)
+    elif kind == "synth" and rng2.integers(3) == 0:
+        # ... and another third change their kind FRAME BY FRAME (silence, noise, wasted bits, resonant, quiet, a channel
+        # that is a copy or the negative of its neighbour): what one frame decides must not leak into the next
+        kind = "mixed"
+        parts = []
+        for f0 in range(0, n, block):
+            m = min(block, n - f0)
+            k2 = str(rng2.choice(["synth", "noise", "silence", "quiet", "sparse", "resonant", "shifted", "twin"]))
+            r3 = np.random.Generator(np.random.PCG64(int(rng2.integers(1 << 30))))
+            if k2 == "resonant" or (k2 == "shifted" and bps < 12):
+                part = synth_hi(int(r3.integers(1 << 30)), channels, bps, m, segment=max(16, m), orders=[int(r3.integers(1, 33))])
+            elif k2 == "twin":
+                part = make_signal(r3, "synth", channels, bps, m).reshape(-1, channels).copy()
+                for c in range(1, channels, 2):
+                    part[:, c] = part[:, c - 1] if r3.integers(2) else np.clip(-part[:, c - 1].astype(np.int64), -(1 << (bps - 1)), (1 << (bps - 1)) - 1)
+                part = part.reshape(-1)
+            else:
+                part = make_signal(r3, k2, channels, bps, m)
+            parts.append(np.asarray(part, dtype=np.int32))
+        pcm = np.concatenate(parts)
     else:
         pcm = make_signal(rng, kind, channels, bps, n)
     rate = int(rng.choice([8000, 44100, 48000, 96000, 192000, 12345]))
