@@ -576,7 +576,9 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.log2_thr = c->d_log2_thr;
     p.cinfo = c->d_cinfo;
     p.fixed_plan = c->d_fixed;
-    p.cand_plan = c->d_cand;
+    // independent channels: candidate c of a frame is its subframe c, so the candidate stage writes the subframe slots
+    // directly and k_decide has nothing to copy (config 4: 18 MB each way per batch)
+    p.cand_plan = c->stereo4 ? c->d_cand : c->d_out;
     p.out_plan = c->d_out;
     p.lpc = c->d_lpc;
     p.ac = c->d_ac;
