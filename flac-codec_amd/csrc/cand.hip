@@ -44,7 +44,7 @@ bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks
         return false;
     }
     if (B == FN && !p.stereo4) {   // independent channels: the instantiation without mid / side
-        if (kn.cand_gather && p.split_src && p.channels >= 2)   // EXPERIMENT: the channel gathered out of the interleaved batch
+        if (p.xpose)   // 4 / 8 channels read in place from the interleaved batch (load_lane_xpose)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false, true>), dim3(blocks), dim3(WG), 0, st, p);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false>), dim3(blocks), dim3(WG), 0, st, p);

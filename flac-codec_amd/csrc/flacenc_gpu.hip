@@ -67,7 +67,7 @@ Knobs read_knobs() {
     k.force_fir_check = on("FLACGPU_FIR_CHECK");
     k.no_sub64 = on("FLACGPU_NO_SUB64");
     k.no_lpc_fuse = on("FLACGPU_NO_LPC_FUSE");
-    k.cand_gather = on("FLACGPU_CAND_GATHER");
+    k.no_xpose = on("FLACGPU_NO_XPOSE");
     k.lpc_fuse_deep = on("FLACGPU_LPC_FUSE_DEEP");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
@@ -571,6 +571,7 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.inter = nullptr;
     p.split_src = nullptr;
     p.split_dst = nullptr;
+    p.xpose = 0;
     p.window_full = c->d_window_full;
     p.window_last = c->d_window_last;
     p.log2_thr = c->d_log2_thr;
@@ -740,10 +741,19 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
                        B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
                        !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
                          c->knobs.ac_private || c->knobs.experiment_mfma_ac);
+    // 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: four
+    // channels of a frame per workgroup) -- the planar rows, half of the autocorrelation kernel's HBM traffic, are not
+    // written at all; like a DIRECT stereo batch, the caller's buffer is then the only copy of the input
+    const bool xpose = split && c->channels == 8 && c->d_edges && !c->knobs.no_xpose;
     if (split) {
         p.split_src = d_pcm;
-        p.split_dst = c->channels == 1 ? nullptr : c->d_planar;
+        p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;
+        p.xpose = xpose ? 1u : 0u;
         if (c->channels == 1) p.planar = d_pcm;   // [frame][B] with ldb == B (planar_direct)
+        if (xpose) {
+            c->planar_valid = false;
+            c->direct_src = d_pcm;
+        }
     }
     if (!direct && !split) begin(0);
     bool have_orbits = direct || split;

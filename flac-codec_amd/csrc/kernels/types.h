@@ -72,8 +72,12 @@ struct Params {
     const int32_t *inter;
     // SPLIT input: a batch of interleaved INDEPENDENT channels ([frame][sample][channel]) that k_autocorr4's producers
     // split into the planar rows (split_dst = `planar`) while they read it -- no k_deinterleave_n pass; nullptr: not used
+    // split_dst == nullptr with several channels: nobody wants the rows -- XPOSE below
     const int32_t *split_src;
     int32_t *split_dst;
+    // XPOSE (with split_src; 4 or 8 channels): k_cand64 and k_sub64 read the interleaved batch in place as well
+    // (load_lane_xpose), the planar rows are never written
+    uint32_t xpose;
     const double *window_full, *window_last;
     const double *log2_thr;                        // [128], index e + 64
     CandInfo *cinfo;
@@ -163,7 +167,7 @@ struct Knobs {
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          lpc_fuse_deep = false,    // A/B: K4 in the tail of k_autocorr4_deep as well (FLACGPU_LPC_FUSE_DEEP; measured slower)
-         cand_gather = false,      // EXPERIMENT: k_cand64 gathers its channel out of the interleaved batch (FLACGPU_CAND_GATHER)
+         no_xpose = false,         // A/B: 4 / 8 interleaved channels split into planar rows by k_autocorr4 instead of read in place (FLACGPU_NO_XPOSE)
          no_lpc_fuse = false,      // A/B: K4 as a launch of its own behind the direct autocorrelation (FLACGPU_NO_LPC_FUSE)
          no_sub64 = false,         // A/B: frames of 3..8 channels assembled by one workgroup per FRAME (k_frame64) (FLACGPU_NO_SUB64)
          no_cand_pair = false;     // A/B: four waves per frame also for the fast channel choice without LPC (FLACGPU_NO_CAND_PAIR)
