@@ -741,10 +741,11 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
                        B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
                        !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
                          c->knobs.ac_private || c->knobs.experiment_mfma_ac);
-    // 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: four
+    // 4 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: four
     // channels of a frame per workgroup) -- the planar rows, half of the autocorrelation kernel's HBM traffic, are not
     // written at all; like a DIRECT stereo batch, the caller's buffer is then the only copy of the input
-    const bool xpose = split && c->channels == 8 && c->d_edges && !c->knobs.no_xpose;
+    // (8 channels: k_sub64, which needs its edge records; 4: k_frame64<256>)
+    const bool xpose = split && ((c->channels == 8 && c->d_edges) || c->channels == 4) && !c->knobs.no_xpose;
     if (split) {
         p.split_src = d_pcm;
         p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;

@@ -168,7 +168,9 @@ int flacgpu_analyze(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n
  * device work on the results passes its own stream instead.
  * Every entry point makes the context's device current for the duration of the call and restores
  * the caller's device afterwards.
- * Lifetime of d_pcm: interleaved stereo PCM of whole blocks of 1024, 1152, 2048, 2304 or 4096 samples (<= 24 bits), one-channel PCM and planar PCM are read IN PLACE by the analysis and frame kernels -- the
+ * Lifetime of d_pcm: interleaved stereo PCM of whole blocks of 1024, 1152, 2048, 2304 or 4096 samples (<= 24 bits), interleaved
+ * 4- and 8-channel PCM of whole 4096-sample blocks (LPC order 1..16), one-channel PCM and planar PCM are read IN PLACE by the
+ * analysis and frame kernels -- the
  * context keeps no copy (no K0 split pass; this is what the reference's `write(&[i32])` hands over,
  * encode.rs:558).  The buffer must therefore stay valid and unchanged until the batch's results have
  * been fetched (flacgpu_fetch* / flacgpu_verify_device / flacgpu_pack_device included) or the next

@@ -309,3 +309,46 @@ def test_mono_is_read_in_place(monkeypatch):
         for f in range(5):
             rc, fb, _ = orc.encode_frame(oo, 48000, 24, x[f * B:(f + 1) * B].reshape(1, B), frame_number=f)
             assert rc == 0 and d2[o2[f]:o2[f + 1]] == fb, (lpc, f)
+
+
+@pytest.mark.parametrize("ch,bps,n,seed", [(8, 24, 21, 960), (4, 24, 9, 961), (8, 16, 3, 962), (4, 12, 17, 963)])
+def test_four_and_eight_channels_are_read_in_place(monkeypatch, ch, bps, n, seed):
+    """4 / 8 interleaved channels (XPOSE): the candidate and subframe kernels fetch four channels of a frame per workgroup
+    straight from the interleaved batch (transposed through LDS), no planar row is written.  Same bytes as the planar-copy
+    path (FLACGPU_NO_XPOSE), as the K0 path and as the oracle; frame counts that leave a tail behind the XCD-paired
+    workgroup ids; and the consumers that want planar rows afterwards (verification, residual rows) still get them."""
+    from flac_codec_amd.gpu import GpuAnalyzer, host_pack_frames
+
+    x = synth_fast(seed, ch, bps, B * n).reshape(-1, ch).astype(np.int64)
+    x[:, 1] = (x[:, 1] >> 2) << 2                       # two wasted bits on channel 1
+    x[B:2 * B, ch - 2] = 0                              # a silent channel in frame 1
+    x[2 * B:3 * B, 0] = -(1 << (bps - 1))               # rail DC in frame 2
+    x[:, ch - 1] = np.random.Generator(np.random.PCG64(seed)).integers(-(1 << (bps - 1)), 1 << (bps - 1), size=x.shape[0])
+    pcm = np.ascontiguousarray(x.astype(np.int32).reshape(-1))
+    outs = {}
+    for mode in ("xpose", "rows", "k0"):
+        monkeypatch.delenv("FLACGPU_NO_XPOSE", raising=False)
+        monkeypatch.delenv("FLACGPU_NO_DIRECT", raising=False)
+        if mode == "rows":
+            monkeypatch.setenv("FLACGPU_NO_XPOSE", "1")
+        if mode == "k0":
+            monkeypatch.setenv("FLACGPU_NO_DIRECT", "1")
+        an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=n)
+        for rep in range(2):     # the second batch of a context meets the first one's leftovers
+            data, off = an.encode_frames(pcm, n, B, 40 + rep, 192000)
+            outs[(mode, rep)] = (data, off)
+        res, _ = an.verify_device(192000, 41)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0), mode
+        if mode == "xpose":
+            an.analyze(pcm, n, B)
+            plans, subs, resid = an.fetch(n, want_residuals=True)
+            h_data, h_off = host_pack_frames(192000, bps, ch, 41, n, B, plans, subs, resid, threads=2)
+            assert (h_data, h_off) == outs[(mode, 1)]
+        an.close()
+    for rep in range(2):
+        assert outs[("xpose", rep)] == outs[("rows", rep)] == outs[("k0", rep)], rep
+    data, off = outs[("xpose", 0)]
+    oopts = orc_options_for(B, 6, 12, True, True)
+    for f, planar in enumerate(planar_frames(pcm, ch, B)):
+        rc, fb, _ = orc.encode_frame(oopts, 192000, bps, planar, frame_number=40 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f
