@@ -721,7 +721,10 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // autocorrelation, candidate and frame kernels (no K0 split; the ORs come out of k_autocorr4, so
     // k_candinfo runs after it) -- see kernels/autocorr.inc.  The caller's buffer is then the only copy of
     // the input: it must stay valid until the batch's results were fetched (include/flacenc_gpu.h).
-    const bool direct = !packed_bytes && layout == FLACGPU_LAYOUT_INTERLEAVED && direct_input_ok(c, p, last_len);
+    // the in-place kernels fetch 16-byte pieces (vector loads, LDS-DMA): a batch that does not start on a 16-byte boundary
+    // (a view into a larger device buffer) takes the copying K0 path, whose loads are dwords
+    const bool aligned16 = ((uintptr_t)d_pcm & 15u) == 0;
+    const bool direct = !packed_bytes && aligned16 && layout == FLACGPU_LAYOUT_INTERLEAVED && direct_input_ok(c, p, last_len);
     c->planar_valid = !direct;
     c->direct_src = direct ? d_pcm : nullptr;
     if (direct) p.inter = d_pcm;
@@ -729,23 +732,28 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     if (c->d_abs) HIP_TRY(hipMemsetAsync(c->d_abs, 0, sizeof(unsigned long long) * 4 * n_frames, st));
     // K0 (+ OR of every candidate's samples -> wasted bits)
     // (one channel: interleaved and planar are the same bytes -- no copy either)
-    const bool planar_direct = !packed_bytes && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
+    const bool planar_direct = !packed_bytes && aligned16 && (layout == FLACGPU_LAYOUT_PLANAR || c->channels == 1) && (B % 4 == 0) &&
                                last_len == B && !c->knobs.no_direct;
     // Independent channels, interleaved, with LPC: k_autocorr4's producers split the batch into the planar rows while
     // they read it (Params::split_src) -- the K0 pass (8 B per sample at the HBM roofline) disappears.  Needs every
     // frame on the wave kernels (no generic-path frame reads the rows before the autocorrelation has written them).
     // (one channel: the input is its own planar row -- nothing to split, but the ORs still come out of the
     // autocorrelation instead of a k_orbits pass over the batch)
-    const bool split = !direct && !packed_bytes && (layout == FLACGPU_LAYOUT_INTERLEAVED || c->channels == 1) && !c->stereo4 &&
+    const bool split = !direct && !packed_bytes && aligned16 && (layout == FLACGPU_LAYOUT_INTERLEAVED || c->channels == 1) && !c->stereo4 &&
                        c->channels >= 1 && (c->channels >= 2 || planar_direct) && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 &&
                        B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
                        !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
                          c->knobs.ac_private || c->knobs.experiment_mfma_ac);
-    // 4 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: four
-    // channels of a frame per workgroup) -- the planar rows, half of the autocorrelation kernel's HBM traffic, are not
-    // written at all; like a DIRECT stereo batch, the caller's buffer is then the only copy of the input
-    // (8 channels: k_sub64, which needs its edge records; 4: k_frame64<256>)
-    const bool xpose = split && ((c->channels == 8 && c->d_edges) || c->channels == 4) && !c->knobs.no_xpose;
+    // 3, 4 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: a
+    // workgroup fetches a whole frame -- or half of an 8-channel one -- together) -- the planar rows, half of the
+    // autocorrelation kernel's HBM traffic, are not written at all; like a DIRECT stereo batch, the caller's buffer is then
+    // the only copy of the input.  (5, 6 channels: measured -- workgroups of five or six 152-register waves do not pack
+    // onto the four SIMDs, the candidate and subframe kernels lose more (0.09 -> 0.13-0.15, 0.15 -> 0.25-0.27 ms per 67 M
+    // samples) than the autocorrelation gains (0.21 -> 0.14); 7: the same only worse.  They keep the rows.)
+    // (8 channels: k_sub64, which needs its edge records; 3, 4: k_frame64)
+    // (>= 8-bit samples: the transposing buffer lies in the LDS image areas of the frame kernels, sized by the sample width)
+    const uint32_t C_ = c->channels;
+    const bool xpose = split && !c->knobs.no_xpose && c->bps >= 8 && (C_ == 3 || C_ == 4 || (C_ == 8 && c->d_edges));
     if (split) {
         p.split_src = d_pcm;
         p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;
@@ -1162,7 +1170,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     q.frame_off = c->d_frame_off;
     q.cap_bytes = c->packed_cap;
     // (planar rows are read in place unless the caller asked for a copy: FLACGPU_TUNE_COPY_INPUT / FLACGPU_NO_DIRECT)
-    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && !c->knobs.no_direct;
+    const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && !c->knobs.no_direct && ((uintptr_t)d_pcm & 15u) == 0;
     if (planar_direct) p.planar = d_pcm;
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st0));  // + d_orbits
     HIP_TRY(hipEventRecord(c->ev_fork, st0));

@@ -18,7 +18,10 @@ void launch_frame64_4096(const Params &p, const PackParams &q, uint32_t frames, 
     switch (p.channels) {
     case 1: launch_frame64_nt<64, 64>(p, q, frames, lds, st); break;
     case 2: launch_frame64_nt<128, 64>(p, q, frames, lds, st); break;
-    case 3: launch_frame64_nt<192, 64>(p, q, frames, lds, st); break;
+    case 3:
+        if (p.xpose) launch_frame64_nt<192, 64, 16, false, true>(p, q, frames, lds, st);   // the interleaved batch read in place
+        else launch_frame64_nt<192, 64>(p, q, frames, lds, st);
+        break;
     case 4:
         if (p.xpose) launch_frame64_nt<256, 64, 16, false, true>(p, q, frames, lds, st);   // the interleaved batch read in place
         else launch_frame64_nt<256, 64>(p, q, frames, lds, st);

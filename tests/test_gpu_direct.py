@@ -311,10 +311,12 @@ def test_mono_is_read_in_place(monkeypatch):
             assert rc == 0 and d2[o2[f]:o2[f + 1]] == fb, (lpc, f)
 
 
-@pytest.mark.parametrize("ch,bps,n,seed", [(8, 24, 21, 960), (4, 24, 9, 961), (8, 16, 3, 962), (4, 12, 17, 963)])
-def test_four_and_eight_channels_are_read_in_place(monkeypatch, ch, bps, n, seed):
-    """4 / 8 interleaved channels (XPOSE): the candidate and subframe kernels fetch four channels of a frame per workgroup
-    straight from the interleaved batch (transposed through LDS), no planar row is written.  Same bytes as the planar-copy
+@pytest.mark.parametrize("ch,bps,n,seed", [(8, 24, 21, 960), (4, 24, 9, 961), (8, 16, 3, 962), (4, 12, 17, 963), (3, 24, 7, 964),
+                                           (6, 24, 11, 965), (5, 20, 6, 966), (6, 8, 4, 967), (3, 4, 3, 968), (7, 24, 3, 969)])
+def test_interleaved_channels_are_read_in_place(monkeypatch, ch, bps, n, seed):
+    """3, 4 / 8 interleaved channels (XPOSE): the candidate and subframe kernels fetch a whole frame (or half of an 8-channel
+    one) per workgroup straight from the interleaved batch (transposed through LDS), no planar row is written (4-bit samples
+    and 5, 6, 7 channels: the planar rows of k_autocorr4's producers, as before).  Same bytes as the planar-copy
     path (FLACGPU_NO_XPOSE), as the K0 path and as the oracle; frame counts that leave a tail behind the XCD-paired
     workgroup ids; and the consumers that want planar rows afterwards (verification, residual rows) still get them."""
     from flac_codec_amd.gpu import GpuAnalyzer, host_pack_frames
@@ -352,3 +354,29 @@ def test_four_and_eight_channels_are_read_in_place(monkeypatch, ch, bps, n, seed
     for f, planar in enumerate(planar_frames(pcm, ch, B)):
         rc, fb, _ = orc.encode_frame(oopts, 192000, bps, planar, frame_number=40 + f)
         assert rc == 0 and data[off[f]:off[f + 1]] == fb, f
+
+
+def test_batches_that_do_not_start_on_16_bytes_take_the_copying_path():
+    """The in-place kernels fetch 16-byte pieces: a device batch that starts 4, 8 or 12 bytes into its allocation goes through
+    K0 instead -- same bytes, whatever the channel count."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    for ch, bps in ((2, 24), (8, 24), (4, 16), (1, 16), (6, 24)):
+        n = 4
+        pcm = np.ascontiguousarray(synth_fast(990 + ch, ch, bps, B * n))
+        an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=n)
+        want = an.encode_frames(pcm, n, B, 3, 48000)
+        for shift in (1, 2, 3):
+            try:
+                big = torch.zeros(pcm.size + 8, dtype=torch.int32, device="cuda")
+            except RuntimeError as e:
+                pytest.skip(f"torch cannot use the GPU here: {e}")
+            big[shift:shift + pcm.size] = torch.from_numpy(pcm).cuda()
+            view = big[shift:shift + pcm.size]
+            assert view.data_ptr() % 16 == 4 * shift
+            an.encode_device(view.data_ptr(), n, B, 3, 48000)
+            torch.cuda.synchronize()
+            assert an.fetch_frames(n) == want, (ch, shift)
+        an.close()

@@ -181,7 +181,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm-dir", default=os.path.join(ROOT, "flac-codec_amd", "csrc"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_issue_floor.json"))
-    ap.add_argument("--tag", default="r04", help="round tag of the counter collections (profiles/<tag>_b_valu.json, <tag>_cfg2_valu.json ...)")
+    ap.add_argument("--tag", default="r04", help="round tag of the counter collections (profiles/<tag>_c_valu.json, <tag>_cfg2_valu.json ...)")
     ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r03_issue_rate_ubench.json"))
     a = ap.parse_args()
     cost = costs(a.ubench)
@@ -203,9 +203,9 @@ def main():
     ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1ELi0ELb1")
     fr = blocks_of(A("frame64_d.gfx950.s"), "k_frame64ILi128ELi64ELi16ELb1")
     out["config3"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn(f"{T}_b", "k_cand64p"), 32768),
-        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(f"{T}_b", "k_autocorr4")),
-        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_b", "k_frame64")),
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn(f"{T}_c", "k_cand64p"), 32768),
+        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(f"{T}_c", "k_autocorr4")),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_c", "k_frame64")),
     }
     # config 3 on the high-order input: orders 8..12 win (10 taps as the representative instantiation)
     out["config3hi"] = {
