@@ -167,6 +167,7 @@ struct Knobs {
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          lpc_fuse_deep = false,    // A/B: K4 in the tail of k_autocorr4_deep as well (FLACGPU_LPC_FUSE_DEEP; measured slower)
+         no_chunk = false,         // A/B: big in-place batches run as ONE range (FLACGPU_NO_CHUNK)
          no_xpose = false,         // A/B: 4 / 8 interleaved channels split into planar rows by k_autocorr4 instead of read in place (FLACGPU_NO_XPOSE)
          no_lpc_fuse = false,      // A/B: K4 as a launch of its own behind the direct autocorrelation (FLACGPU_NO_LPC_FUSE)
          no_sub64 = false,         // A/B: frames of 3..8 channels assembled by one workgroup per FRAME (k_frame64) (FLACGPU_NO_SUB64)

@@ -81,7 +81,7 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_fetch")
         return plans, subs, res
 
-    TUNE_TWO_RANGES, TUNE_LAG_SPLIT, TUNE_BLOCKING_WAIT, TUNE_COPY_INPUT = 1, 2, 3, 4
+    TUNE_TWO_RANGES, TUNE_LAG_SPLIT, TUNE_BLOCKING_WAIT, TUNE_COPY_INPUT, TUNE_CHUNK_MSAMPLES = 1, 2, 3, 4, 5
 
     def set_tuning(self, key, value):
         rc = _lib.lib().flacgpu_set_tuning(self._h, key, value)

@@ -224,7 +224,13 @@ enum {
      * whatever is fetched later (an LPC order tie re-decided at fetch time, flacgpu_verify_device, residual rows
      * all work from the copy).  0 (default): direct input, the lifetime rule at flacgpu_analyze_device applies.
      * For streaming callers that recycle one input buffer without waiting for their fetch. */
-    FLACGPU_TUNE_COPY_INPUT = 4
+    FLACGPU_TUNE_COPY_INPUT = 4,
+    /* flacgpu_encode_device runs a batch of in-place wave-kernel frames (interleaved whole 4096-sample blocks, LPC order
+     * 1..16, exhaustive channel choice) range by range once it holds more than 1.5 x this many Mi samples: the whole kernel
+     * chain for `value` Mi samples at a time (default 64: the candidate and frame kernels then re-read from the 256 MiB
+     * last-level cache what the autocorrelation streamed; 8-channel batches of 8192 frames: 6-7 % faster).  0: never cut.
+     * The bytes, plans and counters are those of the uncut batch. */
+    FLACGPU_TUNE_CHUNK_MSAMPLES = 5
 };
 int flacgpu_set_tuning(flacgpu_ctx *ctx, int key, int value);
 int flacgpu_encode_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, uint32_t n_frames,

@@ -261,3 +261,40 @@ def test_pack_plans_of_wave_block_frames(channels):
     got, got_off = an.fetch_frames(n)
     assert got_off == want_off and got == want
     an.close()
+
+
+@pytest.mark.parametrize("channels,bps,max_lpc,n_frames,chunk_m", [(8, 24, 12, 700, 8), (2, 24, 12, 1500, 4), (4, 16, 8, 1100, 6),
+                                                                   (3, 24, 12, 900, 4), (6, 24, 12, 600, 8)])
+def test_batches_cut_into_ranges_give_the_same_bytes(channels, bps, max_lpc, n_frames, chunk_m):
+    """flacgpu_encode_device runs a big in-place batch range by range (FLACGPU_TUNE_CHUNK_MSAMPLES; default 64 Mi samples):
+    the whole kernel chain per range, frame offsets continuing from the range before.  With a small range size the same
+    happens to a test-sized batch: same bytes, offsets and counters as the uncut batch, batch after batch; and the verifier
+    and the order-tie / FIR re-checks, which work on the whole batch afterwards, still see all of it."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    block = 4096
+    pcm = np.ascontiguousarray(synth_fast(800 + channels, channels, bps, n_frames * block))
+    try:
+        d = torch.from_numpy(pcm).cuda()
+    except RuntimeError as e:
+        pytest.skip(f"torch cannot use the GPU here: {e}")
+    whole = GpuAnalyzer(block, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n_frames)
+    whole.set_tuning(whole.TUNE_CHUNK_MSAMPLES, 0)
+    cut = GpuAnalyzer(block, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n_frames)
+    cut.set_tuning(cut.TUNE_CHUNK_MSAMPLES, chunk_m)
+    assert n_frames * block * channels > 1.5 * (chunk_m << 20)
+    for call in range(2):
+        whole.encode_device(d.data_ptr(), n_frames, block, 77 * call, 96000)
+        cut.encode_device(d.data_ptr(), n_frames, block, 77 * call, 96000)
+        torch.cuda.synchronize()
+        want = whole.fetch_frames(n_frames)
+        got = cut.fetch_frames(n_frames)
+        assert got[1] == want[1] and got[0] == want[0], call
+    sw, sc = whole.stats(), cut.stats()
+    assert (sw.order_ties, sw.fir_recheck) == (sc.order_ties, sc.fir_recheck)
+    res, _ = cut.verify_device(96000, 77)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n_frames, 0, 0, 0)
+    whole.close()
+    cut.close()
