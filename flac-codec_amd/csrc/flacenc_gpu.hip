@@ -165,6 +165,7 @@ struct flacgpu_ctx {
     // frames [rng_f0, rng_f0 + rng_cnt) only; rng_cnt == 0: the whole batch
     uint32_t rng_f0 = 0, rng_cnt = 0;
     uint32_t chunk_samples = 64u << 20;   // FLACGPU_TUNE_CHUNK_MSAMPLES (0: never cut)
+    bool chunk_auto = true;               // nobody set the tuning: only stereo batches are cut (measured: +9 %; 8 channels: +-0)
     bool planar_valid = true;       // false: the last batch was analysed from the caller's interleaved PCM in
     const int32_t *direct_src = nullptr;   //   place (direct_src); d_planar is filled on demand (ensure_planar)
     Params last_params;
@@ -1146,7 +1147,10 @@ int flacgpu_set_tuning(flacgpu_ctx *c, int key, int value) {
     if (!c) return FLACGPU_ERR_INVALID_ARG;
     switch (key) {
     case FLACGPU_TUNE_TWO_RANGES: c->two_ranges = value != 0; return FLACGPU_OK;
-    case FLACGPU_TUNE_CHUNK_MSAMPLES: c->chunk_samples = value <= 0 ? 0u : (uint32_t)std::min(value, 2047) << 20; return FLACGPU_OK;
+    case FLACGPU_TUNE_CHUNK_MSAMPLES:
+        c->chunk_samples = value <= 0 ? 0u : (uint32_t)std::min(value, 2047) << 20;
+        c->chunk_auto = false;
+        return FLACGPU_OK;
     case FLACGPU_TUNE_COPY_INPUT:
         // its own flag: turning the tuning off must not cancel an environment FLACGPU_NO_DIRECT=1
         c->copy_input = value != 0;
@@ -1175,6 +1179,7 @@ static uint32_t chunk_frames(const flacgpu_ctx *c, const int32_t *d_pcm, int lay
     const uint32_t B = c->opts.block_size;
     const Knobs &kn = c->knobs;
     if (!c->chunk_samples || kn.no_chunk || c->timing || c->lag_split == 2 || B != FN || last_len != B || layout != FLACGPU_LAYOUT_INTERLEAVED) return 0;
+    if (c->chunk_auto && !c->stereo4) return 0;   // independent channels: only on request (config 4: no gain measured)
     if (((uintptr_t)d_pcm & 15u) || kn.no_direct || kn.no_fast || kn.no_w64 || kn.no_ac3 || kn.ac_private || kn.experiment_mfma_ac ||
         kn.no_lpc_fuse || kn.no_fused_pack || kn.no_frame64 || kn.no_persist)
         return 0;
@@ -1222,9 +1227,9 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         }
         // A batch of more samples than the chip's last-level cache likes (256 MiB of Infinity Cache: the candidate and
         // frame kernels re-read what the autocorrelation just streamed) is run range by range -- the whole kernel chain for
-        // ~64 Mi samples at a time, each range's frame offsets continuing from the one before (k_layout): 8-channel
-        // batches of 8192 frames (268 M samples) run 6-7 % faster as four ranges of 2048 (bench.py batch_sweep: the
-        // per-sample rate peaks at 67 M samples per batch for 2 and for 8 channels alike).
+        // ~64 Mi samples at a time, each range's frame offsets continuing from the one before (k_layout): a stereo batch of
+        // 16384 frames (134 M samples) runs 9 % faster as two ranges of 8192 (profiles/r04_chunk_ab.json; 8-channel batches
+        // of 8192 frames as four ranges: no difference, so independent channels are cut only when the tuning asks).
         const uint32_t chunk = chunk_frames(c, d_pcm, layout, n_frames, last_len);
         if (chunk) {
             int rc = FLACGPU_OK;

@@ -227,9 +227,9 @@ enum {
     FLACGPU_TUNE_COPY_INPUT = 4,
     /* flacgpu_encode_device runs a batch of in-place wave-kernel frames (interleaved whole 4096-sample blocks, LPC order
      * 1..16, exhaustive channel choice) range by range once it holds more than 1.5 x this many Mi samples: the whole kernel
-     * chain for `value` Mi samples at a time (default 64: the candidate and frame kernels then re-read from the 256 MiB
-     * last-level cache what the autocorrelation streamed; 8-channel batches of 8192 frames: 6-7 % faster).  0: never cut.
-     * The bytes, plans and counters are those of the uncut batch. */
+     * chain for `value` Mi samples at a time.  Default: 64, stereo batches only (16384-frame batches: + 9 %; 8-channel batches
+     * measured no gain and are cut only once this tuning has been set).  0: never cut.  The bytes, plans and counters are
+     * those of the uncut batch. */
     FLACGPU_TUNE_CHUNK_MSAMPLES = 5
 };
 int flacgpu_set_tuning(flacgpu_ctx *ctx, int key, int value);

@@ -104,6 +104,39 @@ def test_full_size_short_blocks_read_in_place(block, bps, lpc, exhaustive, mid_s
         assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
 
 
+def test_stereo_batches_beyond_96_mi_samples_are_cut_in_ranges():
+    """Twice the bench's batch (16384 stereo frames, 134 M samples) in ONE flacgpu_encode_device call is run as two ranges of
+    8192 frames by default (FLACGPU_TUNE_CHUNK_MSAMPLES): the bytes of the uncut batch, every frame decoding back to its input
+    on the device, sampled frames equal to the oracle's."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    frames = 16384
+    pcm = tiled(771, 2, 24, frames, block=4096, distinct=509)
+    try:
+        d = torch.from_numpy(pcm).cuda()
+    except RuntimeError as e:
+        pytest.skip(f"torch cannot use the GPU here: {e}")
+    outs = []
+    for chunk in (None, 0):
+        an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=frames)
+        if chunk is not None:
+            an.set_tuning(an.TUNE_CHUNK_MSAMPLES, chunk)
+        an.encode_device(d.data_ptr(), frames, 4096, 9, 48000)
+        outs.append(an.fetch_frames(frames))
+        res, _ = an.verify_device(48000, 9)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs, res.samples_differ) == (frames, 0, 0, 0, 0)
+        an.close()
+    assert outs[0] == outs[1]
+    data, off = outs[0]
+    oo = orc_options_for(4096, 6, 12, True, True)
+    for f in (0, 8191, 8192, 8193, frames - 1):
+        blk = pcm[f * 4096 * 2:(f + 1) * 4096 * 2].reshape(4096, 2).T
+        rc, fb, _ = orc.encode_frame(oo, 48000, 24, np.ascontiguousarray(blk), frame_number=9 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"frame {f} differs from the oracle"
+
+
 def test_batch_size_independence():
     """The same stream encoded with different GPU batch sizes gives identical bytes."""
     from flac_codec_amd.encode import FlacSampleWriter, Options

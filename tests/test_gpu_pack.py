@@ -285,6 +285,14 @@ def test_batches_cut_into_ranges_give_the_same_bytes(channels, bps, max_lpc, n_f
     cut = GpuAnalyzer(block, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n_frames)
     cut.set_tuning(cut.TUNE_CHUNK_MSAMPLES, chunk_m)
     assert n_frames * block * channels > 1.5 * (chunk_m << 20)
+    if channels == 2:    # stereo batches are cut without being asked, at 64 Mi samples: the default must not change bytes either
+        dflt = GpuAnalyzer(block, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=n_frames)
+        dflt.encode_device(d.data_ptr(), n_frames, block, 0, 96000)
+        torch.cuda.synchronize()
+        whole.encode_device(d.data_ptr(), n_frames, block, 0, 96000)
+        torch.cuda.synchronize()
+        assert dflt.fetch_frames(n_frames) == whole.fetch_frames(n_frames)
+        dflt.close()
     for call in range(2):
         whole.encode_device(d.data_ptr(), n_frames, block, 77 * call, 96000)
         cut.encode_device(d.data_ptr(), n_frames, block, 77 * call, 96000)
