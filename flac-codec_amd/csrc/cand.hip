@@ -46,7 +46,7 @@ bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks
     if (B == FN && !p.stereo4) {   // independent channels: the instantiation without mid / side
         if (p.xpose) {   // 3, 4 / 8 channels read in place from the interleaved batch (load_lane_xpose): CW waves per workgroup
             const uint32_t cands = p.fcount * p.ncand;
-            if (p.channels == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false, 3>), dim3(cands / 3), dim3(192), 0, st, p);
+            if (p.channels == 3 || p.channels == 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false, 3>), dim3(cands / 3), dim3(192), 0, st, p);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_cand64<64, 16, false, 4>), dim3(cands / 4), dim3(WG), 0, st, p);
         }
         else

@@ -753,16 +753,16 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
                        B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
                        !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
                          c->knobs.ac_private || c->knobs.experiment_mfma_ac);
-    // 3, 4 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: a
-    // workgroup fetches a whole frame -- or half of an 8-channel one -- together) -- the planar rows, half of the
+    // 3, 4, 6 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: a
+    // workgroup fetches a whole frame -- or half of a 6- or 8-channel one -- together) -- the planar rows, half of the
     // autocorrelation kernel's HBM traffic, are not written at all; like a DIRECT stereo batch, the caller's buffer is then
-    // the only copy of the input.  (5, 6 channels: measured -- workgroups of five or six 152-register waves do not pack
-    // onto the four SIMDs, the candidate and subframe kernels lose more (0.09 -> 0.13-0.15, 0.15 -> 0.25-0.27 ms per 67 M
-    // samples) than the autocorrelation gains (0.21 -> 0.14); 7: the same only worse.  They keep the rows.)
-    // (8 channels: k_sub64, which needs its edge records; 3, 4: k_frame64)
+    // the only copy of the input.  (Whole frames of 5 or 6 channels in one workgroup: measured -- five or six 152-register
+    // waves do not pack onto the four SIMDs, the candidate and subframe kernels lose more (0.09 -> 0.13-0.15, 0.15 ->
+    // 0.25-0.27 ms per 67 M samples) than the autocorrelation gains (0.21 -> 0.14); 5 and 7 channels keep the rows.)
+    // (6, 8 channels: k_sub64, which needs its edge records; 3, 4: k_frame64)
     // (>= 8-bit samples: the transposing buffer lies in the LDS image areas of the frame kernels, sized by the sample width)
     const uint32_t C_ = c->channels;
-    const bool xpose = split && !c->knobs.no_xpose && c->bps >= 8 && (C_ == 3 || C_ == 4 || (C_ == 8 && c->d_edges));
+    const bool xpose = split && !c->knobs.no_xpose && c->bps >= 8 && (C_ == 3 || C_ == 4 || ((C_ == 8 || C_ == 6) && c->d_edges));
     if (split) {
         p.split_src = d_pcm;
         p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;

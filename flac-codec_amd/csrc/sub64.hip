@@ -18,7 +18,10 @@ void launch_sub64(const Params &p, const PackParams &q, uint32_t frames, hipStre
     // the image: a subframe never exceeds its VERBATIM form (encode.rs:2970-2979), subframe 0 carries the <= 16-byte
     // frame header; + the lead bits, the (w0 & 3) shift that aligns LDS with the output, two guard words
     const uint32_t words = ((((FN * p.bps + 8u + 32u + 128u + 31u + 31u) / 32u) + 3u + 2u + 3u) & ~3u) + 4u;   // (+ a guard group in front)
-    if (p.xpose) {   // 8 channels: four channels of a frame per workgroup, fetched together from the interleaved batch
+    if (p.xpose && p.channels == 6) {   // two workgroups of three waves per frame (load_lane_xpose_half6)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub64<64, 16, 3>), dim3(frames * 2), dim3(192), 3 * (size_t)words * sizeof(uint32_t), st, p, q,
+                           words);
+    } else if (p.xpose) {   // 8 channels: four channels of a frame per workgroup, fetched together from the interleaved batch
         // (<= 25-bit samples: the four images are < 64 KB; they also hold the 8 KB transposing buffer: bps >= 8)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sub64<64, 16, 4>), dim3(frames * p.channels / 4), dim3(256),
                            4 * (size_t)words * sizeof(uint32_t), st, p, q, words);

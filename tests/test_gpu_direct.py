@@ -312,11 +312,11 @@ def test_mono_is_read_in_place(monkeypatch):
 
 
 @pytest.mark.parametrize("ch,bps,n,seed", [(8, 24, 21, 960), (4, 24, 9, 961), (8, 16, 3, 962), (4, 12, 17, 963), (3, 24, 7, 964),
-                                           (6, 24, 11, 965), (5, 20, 6, 966), (6, 8, 4, 967), (3, 4, 3, 968), (7, 24, 3, 969)])
+                                           (6, 24, 11, 965), (5, 20, 6, 966), (6, 8, 4, 967), (3, 4, 3, 968), (7, 24, 3, 969), (6, 16, 19, 970)])
 def test_interleaved_channels_are_read_in_place(monkeypatch, ch, bps, n, seed):
-    """3, 4 / 8 interleaved channels (XPOSE): the candidate and subframe kernels fetch a whole frame (or half of an 8-channel
-    one) per workgroup straight from the interleaved batch (transposed through LDS), no planar row is written (4-bit samples
-    and 5, 6, 7 channels: the planar rows of k_autocorr4's producers, as before).  Same bytes as the planar-copy
+    """3, 4, 6 / 8 interleaved channels (XPOSE): the candidate and subframe kernels fetch a whole frame (or half of a 6- or
+    8-channel one) per workgroup straight from the interleaved batch (transposed through LDS), no planar row is written
+    (4-bit samples and 5, 7 channels: the planar rows of k_autocorr4's producers, as before).  Same bytes as the planar-copy
     path (FLACGPU_NO_XPOSE), as the K0 path and as the oracle; frame counts that leave a tail behind the XCD-paired
     workgroup ids; and the consumers that want planar rows afterwards (verification, residual rows) still get them."""
     from flac_codec_amd.gpu import GpuAnalyzer, host_pack_frames

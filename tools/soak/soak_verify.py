@@ -6,7 +6,7 @@ from _pcm import synth_fast
 SECONDS = float(os.environ.get("SOAK_SECONDS", "120"))
 F, B = 4096, 4096
 rng = np.random.Generator(np.random.PCG64(5))
-cfgs = [(2, 24, 12), (2, 16, 8), (1, 24, 12), (2, 24, 32), (4, 20, 12), (8, 24, 12), (6, 16, 8)]   # (the last two: k_sub64, r04)
+cfgs = [(2, 24, 12), (2, 16, 8), (1, 24, 12), (2, 24, 32), (4, 20, 12), (8, 24, 12), (6, 16, 8), (3, 24, 12), (8, 16, 10)]   # (8 / 6: k_sub64; 3, 4, 8: read in place, r04)
 tot_frames = tot_batches = 0
 t_end = time.time() + SECONDS
 per = SECONDS / len(cfgs)
