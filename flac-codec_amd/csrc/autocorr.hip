@@ -144,8 +144,10 @@ void launch_autocorr(const Params &p, uint32_t frame0, uint32_t nframes, uint32_
 }  // namespace
 
 namespace flacgpu_k {
-bool dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
+bool dispatch_autocorr(uint32_t H, const Params &p_in, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
                        const double *win, hipStream_t st) {
+    Params p = p_in;
+    if (n != p.block_size) p.fma_t0 = p.fma_t1 = 0;   // a short last frame has a window of its own: no fused tiles
     // EXPERIMENT switch (bench.py --experiment mfma_autocorr): the re-associating f64-MFMA kernel in
     // place of the exact one, to measure what a whole step costs with the autocorrelation off the
     // VALU pipe.  NOT bit-exact; never set in production.

@@ -69,6 +69,7 @@ Knobs read_knobs() {
     k.no_lpc_fuse = on("FLACGPU_NO_LPC_FUSE");
     k.no_xpose = on("FLACGPU_NO_XPOSE");
     k.no_chunk = on("FLACGPU_NO_CHUNK");
+    k.no_ac_fma = on("FLACGPU_NO_AC_FMA");
     k.lpc_fuse_deep = on("FLACGPU_LPC_FUSE_DEEP");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
@@ -164,6 +165,7 @@ struct flacgpu_ctx {
     // a batch cut into frame ranges by flacgpu_encode_device (chunk_frames): analyze_impl / pack_impl launch their kernels for
     // frames [rng_f0, rng_f0 + rng_cnt) only; rng_cnt == 0: the whole batch
     uint32_t rng_f0 = 0, rng_cnt = 0;
+    uint32_t flat_lo = 0, flat_hi = 0;    // samples [flat_lo, flat_hi) of a full block lie under window values of exactly 1.0
     uint32_t chunk_samples = 64u << 20;   // FLACGPU_TUNE_CHUNK_MSAMPLES (0: never cut)
     bool chunk_auto = true;               // nobody set the tuning: only stereo batches are cut (measured: +9 %; 8 channels: +-0)
     bool planar_valid = true;       // false: the last batch was analysed from the caller's interleaved PCM in
@@ -282,6 +284,16 @@ void build_log2_thresholds(double *thr) {
 int upload_window(flacgpu_ctx *c, uint32_t n, double *dst, hipStream_t st) {
     std::vector<double> w;
     window_generate(c->opts.window_kind, c->opts.window_param, n, w);
+    if (dst == c->d_window_full) {
+        // the run of window values that are EXACTLY 1.0 (the flat middle of a Tukey window; empty for the others): samples
+        // under it stay integers when windowed, which is what lets k_autocorr4 fuse multiply and add there (Params::fma_t0)
+        uint32_t lo = 0;
+        while (lo < n && w[lo] != 1.0) lo++;
+        uint32_t hi = lo;
+        while (hi < n && w[hi] == 1.0) hi++;
+        c->flat_lo = lo;
+        c->flat_hi = hi;   // [lo, hi)
+    }
     w.resize((size_t)n + 64, 0.0);
     HIP_TRY(hipMemcpyAsync(dst, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // `w` is a local
@@ -573,6 +585,13 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.f0 = 0;
     p.fcount = n_frames;
     p.ac_split = (uint32_t)c->lag_split;
+    p.fma_t0 = p.fma_t1 = 0;
+    // integer samples below 2^26 (candidates of <= 25 bits + the side channel's extra bit) have exact f64 products
+    if (!c->knobs.no_ac_fma && c->bps + (c->stereo4 ? 1u : 0u) <= 26u && c->flat_hi > c->flat_lo) {
+        const uint32_t maxlag = c->opts.max_lpc_order;
+        p.fma_t0 = (c->flat_lo + maxlag + 31u) / 32u;      // first 32-sample tile whose every partner sample is flat too
+        p.fma_t1 = c->flat_hi / 32u;                        // tiles t < fma_t1 end inside the flat run
+    }
     p.planar = c->d_planar;
     p.inter = nullptr;
     p.split_src = nullptr;
@@ -2042,6 +2061,7 @@ void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     case 3: return ensure_planar(c) == FLACGPU_OK ? c->d_planar : nullptr;
     case 4: return c->d_packed;
     case 5: return c->d_frame_off;
+    case 6: return c->d_ac;
     default: return nullptr;
     }
 }

@@ -64,6 +64,10 @@ struct Params {
     uint32_t n_frames, last_len;
     uint32_t f0, fcount;                           // frames [f0, f0 + fcount) handled by this launch
     uint32_t ac_split;                             // waves the lags of k_autocorr3 are split over (2 or 4)
+    // k_autocorr4 / _deep: 32-sample tiles [fma_t0, fma_t1) of a FULL block whose every product has both factors under window
+    // values of exactly 1.0 (and integer samples below 2^26): there a term is one v_fma_f64, bit-identical to the reference's
+    // multiply + add because the product is exact.  fma_t0 >= fma_t1: nowhere (short last frame, other windows, wide samples)
+    uint32_t fma_t0, fma_t1;
     // buffers
     const int32_t *planar;
     // DIRECT input: the batch's interleaved stereo PCM ([frame][sample][l, r], every frame of block_size
@@ -167,6 +171,7 @@ struct Knobs {
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          lpc_fuse_deep = false,    // A/B: K4 in the tail of k_autocorr4_deep as well (FLACGPU_LPC_FUSE_DEEP; measured slower)
+         no_ac_fma = false,        // A/B: every autocorrelation term a multiply and an add (FLACGPU_NO_AC_FMA)
          no_chunk = false,         // A/B: big in-place batches run as ONE range (FLACGPU_NO_CHUNK)
          no_xpose = false,         // A/B: 4 / 8 interleaved channels split into planar rows by k_autocorr4 instead of read in place (FLACGPU_NO_XPOSE)
          no_lpc_fuse = false,      // A/B: K4 as a launch of its own behind the direct autocorrelation (FLACGPU_NO_LPC_FUSE)

@@ -185,7 +185,8 @@ int flacgpu_get_stats(flacgpu_ctx *ctx, flacgpu_stats *out);
 
 /* Device pointers of the last analysis (for callers that chain further device work):
  * which: 0 frame plans, 1 subframe plans, 2 residuals, 3 planar pcm, 4 packed frame bytes,
- * 5 frame byte offsets (uint64[n_frames + 1]). */
+ * 5 frame byte offsets (uint64[n_frames + 1]), 6 the autocorrelation of every candidate (double[n_frames * candidates][36]:
+ * lags 0 .. max_lpc_order of the windowed samples, encode.rs:3403-3413 -- bit for bit the reference's sums). */
 void *flacgpu_device_buffer(flacgpu_ctx *ctx, int which);
 
 /* ---- device-side frame assembly ---------------------------------
