@@ -595,8 +595,9 @@ class Workload:
 
     def kernels_report(self, compressed_bytes):
         """Per-kernel durations priced against each kernel's own bound: HBM bytes for the integer kernels, separately
-        rounded f64 mul+add for the autocorrelation (no FMA is allowed there: 39.3 TFLOP/s is what the f64 VALU can
-        issue as mul + add; the datasheet's 78.6 TFLOP/s counts an FMA as two)."""
+        rounded f64 mul+add for the autocorrelation (an FMA is bit-identical only where the product is exact -- under
+        window values of exactly 1.0, about half of a Tukey(0.5) block, where the kernels do fuse; elsewhere 39.3 TFLOP/s
+        is what the f64 VALU can issue as mul + add; the datasheet's 78.6 TFLOP/s counts an FMA as two)."""
         acc = self.kernel_times()
         alg = self.algorithmic(compressed_bytes)
         kernels = {}
@@ -640,8 +641,10 @@ def roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale):
              "unit": "TFLOP/s", "frac": round(k["GFLOP/s"] / F64_PEAK_GFLOPS, 4),
              "frac_of_mul_add_peak_39.3": round(k["GFLOP/s"] / (F64_PEAK_GFLOPS / 2), 4),
              "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops": amount,
-             "note": "exact left-fold autocorrelation: separately rounded f64 mul and add on the VALU (an FMA or a matrix "
-                     "core would change the sums); 78.6 TFLOP/s is the stated f64 peak, 39.3 what mul + add can reach"}
+             "note": "exact left-fold autocorrelation on the VALU: separately rounded f64 mul and add under the window's "
+                     "taper (an FMA or a matrix core would change the sums there), one FMA per term under its flat middle "
+                     "(integer factors, exact product: identical rounding); 78.6 TFLOP/s is the stated f64 peak, 39.3 what "
+                     "mul + add can reach"}
     r["avg_launch_ms"] = k["ms"]
     r["dominance_rule"] = ("longest launch among the priced kernels (HBM bytes or f64 flops); launches within 3 % are tied, "
                            "an HBM-priced kernel wins a tie (every kernel's own fraction is in kernels.*)")
