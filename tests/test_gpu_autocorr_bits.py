@@ -72,3 +72,35 @@ def test_autocorrelation_is_the_references_bit_for_bit(monkeypatch, ch, bps, lpc
             assert np.array_equal(have.view(np.int64), want.view(np.int64)), (f, c, have, want)
             checked += 1
     assert checked >= n * ncand - 2
+
+
+@pytest.mark.parametrize("ch,bps,last", [(2, 24, 1000), (2, 16, 4032), (4, 24, 2500), (1, 24, 64)])
+def test_short_last_frame_keeps_its_own_window(ch, bps, last):
+    """A batch whose last frame is short: the full frames go through the fused tiles of the full block's window, the last
+    frame through a launch of its own with the window of its length (no fused tiles there) -- every row bit for bit."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    n, lpc = 5, 12
+    total = (n - 1) * B + last
+    x = synth_fast(70 + ch + bps, ch, bps, total).reshape(-1, ch).astype(np.int64)
+    pcm = np.ascontiguousarray(x.astype(np.int32).reshape(-1))
+    stereo = ch == 2
+    ncand = 4 if stereo else ch
+    an = GpuAnalyzer(B, 6, lpc, True, True, 2, 0.5, bps, ch, max_frames=n)
+    an.analyze(pcm, n, last)
+    an.stats()
+    got = device_ac(an, n * ncand)[:, : lpc + 1].copy()
+    an.close()
+    for f in range(n):
+        length = B if f < n - 1 else last
+        w = orc.window(2, 0.5, length)
+        frame = x[f * B:f * B + length].T
+        for c, row in enumerate(candidates_of(frame, stereo)):
+            row = np.asarray(row, dtype=np.int64)
+            orv = int(np.bitwise_or.reduce(row))
+            if orv == 0:
+                continue
+            wasted = (orv & -orv).bit_length() - 1
+            want = orc.autocorrelate((row >> wasted).astype(np.float64) * w, lpc)
+            have = got[f * ncand + c][: len(want)]
+            assert np.array_equal(have.view(np.int64), want.view(np.int64)), (f, c)
