@@ -588,7 +588,8 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.fma_t0 = p.fma_t1 = 0;
     // integer samples below 2^26 (candidates of <= 25 bits + the side channel's extra bit) have exact f64 products
     if (!c->knobs.no_ac_fma && c->bps + (c->stereo4 ? 1u : 0u) <= 26u && c->flat_hi > c->flat_lo) {
-        const uint32_t maxlag = c->opts.max_lpc_order;
+        // (the margin is the most lags a launch can carry -- its lag count is the order + 1 rounded up to four --, not the order)
+        const uint32_t maxlag = c->opts.max_lpc_order <= 16 ? 16u : 32u;
         p.fma_t0 = (c->flat_lo + maxlag + 31u) / 32u;      // first 32-sample tile whose every partner sample is flat too
         p.fma_t1 = c->flat_hi / 32u;                        // tiles t < fma_t1 end inside the flat run
     }
