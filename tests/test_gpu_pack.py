@@ -306,3 +306,15 @@ def test_batches_cut_into_ranges_give_the_same_bytes(channels, bps, max_lpc, n_f
     assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n_frames, 0, 0, 0)
     whole.close()
     cut.close()
+
+
+@pytest.mark.parametrize("channels,block", [(8, 4096), (4, 4096), (3, 4096), (6, 4096), (2, 4096), (2, 1152), (1, 4096), (5, 4096)])
+def test_frame_headers_of_every_frame_kernel(channels, block):
+    """The frame header (sync, codes, UTF-8-like frame number of 1..7 bytes, block-size / sample-rate tails, CRC-8) is
+    written by one lane from registers in every frame kernel -- k_frame64 (1..4 channels, in place and from rows),
+    k_sub64 (one wave or four per workgroup) --: frame numbers at every length boundary and rates with 0-, 1- and 2-byte
+    tails against the oracle, for the channel counts that select each of them."""
+    pcm = synth_fast(230 + channels, channels, 24, block * 3)
+    for first, rate in ((0, 48000), (0x7E, 44100), (0x7FE, 192000), (0xFFFE, 12345), (0x1FFFFE, 352800), (0x3FFFFFE, 655350),
+                        (0x7FFFFFFE, 7000), (0xFFFFFFFF0, 96000)):
+        run_case(pcm, channels, 24, block_size=block, first_frame=first, rate=rate)
