@@ -796,6 +796,120 @@ def measure_other_config(torch, cfg_id, args, device, orc, signal="ar2"):
     return out
 
 
+FINAL_LINE_LIMIT = 8192      # hard cap of the record the driver parses (a 21 KB line did not parse)
+FINAL_LINE_TARGET = 4096
+
+
+def _pick(d, *keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+def _short(text, n):
+    return text if text is None or len(text) <= n else text[: n - 3] + "..."
+
+
+def compact_record(out, detail_path=None):
+    """The record printed as the LAST stdout line: the driver's contract keys, `roofline`, `cpu_baseline` and a dozen
+    scalar extras -- no prose, no per-config blocks.  Everything else (other_configs, batch_sweep, end_to_end, kernels,
+    notes) lives in the detail file written beside it (`write_detail`)."""
+    cfgd = out.get("config") or {}
+    rec = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    rec["config"] = {"workload": _short(cfgd.get("workload"), 200), "baseline_config": cfgd.get("baseline_config"),
+                     "level": cfgd.get("level"), "frames_per_step": cfgd.get("frames_per_step"),
+                     "frames_per_gpu": cfgd.get("frames_per_gpu"), "contexts": cfgd.get("contexts"),
+                     "parallelism": cfgd.get("parallelism")}
+    r = out.get("roofline")
+    if r:
+        rr = _pick(r, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes",
+                   "algorithmic_flops", "avg_launch_ms", "counters_stale")
+        rec["roofline"] = {k: v for k, v in rr.items() if v is not None or k in ("traffic", "counters_stale")}
+        v = r.get("valu_issue") or {}
+        if v.get("frac_of_attainable") is not None:
+            rec["roofline"]["frac_of_issue_floor"] = v["frac_of_attainable"]
+    else:
+        rec["roofline"] = None
+    c = out.get("cpu_baseline")
+    if c:
+        rec["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                               "sample": _short(c.get("sample"), 160)}
+        for k in ("reference_fork_join", "all_cores_frame_parallel"):
+            if c.get(k):
+                rec["cpu_baseline"][k] = _pick(c[k], "value", "cores")
+    else:
+        rec["cpu_baseline"] = None
+    extras = {"build_id": out.get("build_id"), "hbm_bound_fraction": out.get("hbm_bound_fraction"),
+              "compression_ratio": out.get("compression_ratio"), "experiment": out.get("experiment")}
+    if out.get("sustained"):
+        extras["sustained_ms_per_step"] = out["sustained"]["ms_per_step"]
+    var = out.get("variants") or {}
+    if var.get("one_context_back_to_back"):
+        extras["one_context_ms_per_step"] = var["one_context_back_to_back"]["ms_per_step"]
+
+    def cfg_scalars(e):
+        d = e.get("dominant_kernel") or {}
+        return {"ms_per_step": e.get("ms_per_step"), "kernel": d.get("kernel"), "kernel_ms": d.get("avg_launch_ms"),
+                "frac": d.get("frac"), "identical": e.get("frames_byte_identical_to_oracle"),
+                "checked": e.get("frames_checked")}
+
+    if var.get("high_order_input"):
+        extras["high_order"] = cfg_scalars(var["high_order_input"])
+    for name, e in sorted((out.get("other_configs") or {}).items()):
+        extras[name] = cfg_scalars(e)
+        if e.get("high_order_input"):
+            extras[name + "_high_order"] = cfg_scalars(e["high_order_input"])
+    kern = out.get("kernels") or {}
+    extras["kernel_ms"] = {k: v.get("ms") for k, v in kern.items()}
+    p = out.get("parity") or {}
+    extras["parity"] = {"identical_per_rank": p.get("frames_byte_identical_to_oracle_per_rank"),
+                        "checked_per_rank": p.get("frames_checked_per_rank"),
+                        "round_tripped_per_rank": p.get("frames_round_tripped_on_device_per_rank"),
+                        "ranks": p.get("ranks_checked")}
+    st = out.get("analysis_stats") or {}
+    extras["fir_recheck"] = st.get("fir_recheck")
+    e2e = out.get("end_to_end") or {}
+    pp = e2e.get("pipelined_pcie") if isinstance(e2e, dict) else None
+    if isinstance(pp, dict):
+        extras["pipelined_pcie"] = {k: _pick(pp[k], "Msamples/s", "frac_of_link") for k in ("int32", "packed_3_byte")
+                                    if isinstance(pp.get(k), dict)}
+    sc = out.get("shard_counters")
+    if isinstance(sc, dict):
+        extras["shards"] = _pick(sc, "ranks_seen", "backend", "total_frames", "total_bytes", "min_frame", "max_frame")
+    rec["extra"] = extras
+    rec["detail"] = detail_path
+    return rec
+
+
+def final_line(out, detail_path=None):
+    """Strict JSON, one line, below FINAL_LINE_LIMIT bytes whatever the detail holds: extras are dropped (largest first)
+    if a future block ever pushes the record over the target."""
+    rec = compact_record(out, detail_path)
+    line = json.dumps(rec, allow_nan=False, separators=(", ", ": "))
+    extra = rec["extra"]
+    while len(line) > FINAL_LINE_TARGET and extra:
+        biggest = max(extra, key=lambda k: len(json.dumps(extra[k])))
+        del extra[biggest]
+        line = json.dumps(rec, allow_nan=False, separators=(", ", ": "))
+    assert len(line) < FINAL_LINE_LIMIT and "\n" not in line
+    return line
+
+
+def write_detail(out, path):
+    """The full record (every block the compact line leaves out) as a file; returns the path written or None."""
+    for cand in ([path] if path else []) + [os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                                           os.path.join(ROOT, "bench_detail.json")]:
+        try:
+            if os.path.dirname(cand) and not os.path.isdir(os.path.dirname(cand)):
+                continue
+            with open(cand, "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+            return os.path.relpath(cand, ROOT) if cand.startswith(ROOT) else cand
+        except OSError:
+            continue
+    return None
+
+
 def metric_text(cfg, bit_exact):
     what = {2: "level 5 (fixed predictors only), 48kHz/16-bit stereo", 3: "level 8, 48kHz/24-bit stereo",
             4: "level 8, 192kHz/24-bit 8-channel", 5: "level 8 exhaustive (LPC order 32), 96kHz/24-bit stereo"}[cfg]
@@ -840,6 +954,9 @@ def main():
                     help="mfma_autocorr: the f64-MFMA autocorrelation (re-associated sums, NOT bit-exact) in place "
                          "of the exact kernel; the line is labelled and frames that differ from the oracle are "
                          "counted instead of failing the run")
+    ap.add_argument("--detail", default=None,
+                    help="where the full record goes (default: gpurun_out/bench_detail.json if that directory exists, "
+                         "else bench_detail.json beside bench.py); stdout carries ONE compact line")
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="steps of the additional long timed loop reported as `sustained`")
     args = ap.parse_args()
@@ -967,6 +1084,7 @@ def main():
     if rank == 0:
         analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties,
                           "order_ties_resolved_on_host": st.order_ties_resolved, "log2_edge": st.log2_edge,
+                          "fir_recheck": st.fir_recheck, "fir_rechecked": st.fir_rechecked,
                           "candidates": (4 if C == 2 else C) * F}
         kernels, dom, alg = w.kernels_report(compressed_bytes)
         sum_kernels = sum(v["ms"] for v in kernels.values())
@@ -1067,7 +1185,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        detail_path = write_detail(out, args.detail)
+        print(final_line(out, detail_path), flush=True)
 
 
 if __name__ == "__main__":

@@ -85,3 +85,74 @@ def test_dominance_rule_prices_both_kinds():
     assert r["bound"] == "f64-valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - 29400.0 / 78600.0) < 1e-4
     r = bench.roofline_of(kernels, "k_cand64", alg, 280e6, {"source": "x"}, None, False)
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["counters_stale"] is False and r["traffic"] == 280e6
+
+
+def _canned_full_record():
+    """The builder's full r04 record (21 KB as one line: the one the driver could not parse), the canned input of the
+    compact-line test."""
+    return json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+
+
+REQUIRED_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+REQUIRED_ROOFLINE = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "counters_stale")
+REQUIRED_CPU = ("value", "unit", "cores", "kind", "sample")
+
+
+def test_final_line_is_compact_strict_json_with_every_contract_key():
+    """BENCH_r04.json.parsed was null because bench.py printed one 21 KB line.  The last stdout line
+    is a compact record: strict JSON, one line, < 8 KB (target < 4 KB), every contract key present."""
+    import bench
+
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 16000                       # the canned record really is the oversized one
+    line = bench.final_line(full, "gpurun_out/bench_detail.json")
+    assert "\n" not in line and len(line.encode()) < bench.FINAL_LINE_LIMIT
+    assert len(line.encode()) < bench.FINAL_LINE_TARGET, len(line)
+
+    def no_constants(x):
+        raise AssertionError(f"non-strict JSON constant {x}")
+
+    rec = json.loads(line, parse_constant=no_constants)
+    for k in REQUIRED_TOP:
+        assert k in rec, k
+    for k in REQUIRED_ROOFLINE:
+        assert k in rec["roofline"], k
+    for k in REQUIRED_CPU:
+        assert k in rec["cpu_baseline"], k
+    assert rec["config"]["workload"] and "model" not in rec["config"]
+    assert rec["value"] == full["value"] and rec["ms_per_step"] == full["ms_per_step"]
+    assert rec["roofline"]["frac"] == full["roofline"]["frac"]
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-3
+    assert rec["cpu_baseline"]["reference_fork_join"]["value"] == full["cpu_baseline"]["reference_fork_join"]["value"]
+    ex = rec["extra"]
+    assert ex["build_id"] == full["build_id"] and ex["sustained_ms_per_step"] == full["sustained"]["ms_per_step"]
+    assert ex["high_order"]["ms_per_step"] == full["variants"]["high_order_input"]["ms_per_step"]
+    for c in (2, 4, 5):
+        assert ex[f"config{c}"]["ms_per_step"] == full["other_configs"][f"config{c}"]["ms_per_step"]
+    assert ex["parity"]["identical_per_rank"] == ex["parity"]["checked_per_rank"] > 0
+    # no prose beyond the workload / sample strings
+    assert not any(isinstance(v, str) and len(v) > 64 for v in ex.values())
+
+
+def test_final_line_survives_missing_blocks_and_oversized_extras():
+    import bench
+
+    full = _canned_full_record()
+    lean = {k: v for k, v in full.items() if k not in ("other_configs", "end_to_end", "variants", "sustained", "cpu_baseline")}
+    rec = json.loads(bench.final_line(lean))
+    assert rec["cpu_baseline"] is None and rec["roofline"]["kernel"]         # --no-cpu-baseline runs, N > 1 ranks
+    # a future block that blows the extras up is dropped, the contract keys stay
+    full["kernels"] = {f"k_{i}": {"ms": i * 0.001} for i in range(600)}
+    line = bench.final_line(full)
+    assert len(line.encode()) < bench.FINAL_LINE_TARGET
+    rec = json.loads(line)
+    assert "kernel_ms" not in rec["extra"] and rec["roofline"] and rec["cpu_baseline"]
+
+
+def test_detail_file_holds_the_full_record(tmp_path):
+    import bench
+
+    full = _canned_full_record()
+    path = bench.write_detail(full, str(tmp_path / "detail.json"))
+    assert json.load(open(path)) == full

@@ -22,5 +22,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/be
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 3 --warmup 1 $COMMON "$@" > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/valu -- python3 $ROOT/bench.py --steps 3 --warmup 1 $COMMON "$@" > $OUT/valu.log 2>&1 || true
 cd $ROOT
-if [ -n "$FULL" ]; then python3 bench.py --steps 20 --warmup 5 "$@" > $OUT/bench.json 2> $OUT/bench.err; fi
+# the full record goes to bench.json (what summarize_profiles.py copies), the compact driver line to bench_line.json
+if [ -n "$FULL" ]; then python3 bench.py --steps 20 --warmup 5 --detail $OUT/bench.json "$@" > $OUT/bench_line.json 2> $OUT/bench.err; fi
 ls $OUT

@@ -17,12 +17,12 @@ for spec in "$@"; do
   envs=${spec%%:*}; flags=${spec#*:}
   i=$((i+1))
   ( for kv in ${envs//,/ }; do [ -n "$kv" ] && export "$kv"; done
-    timeout 600 python3 bench.py $flags > $OUT/bench_$i.json 2> $OUT/bench_$i.err
+    timeout 600 python3 bench.py --detail $OUT/bench_$i.json $flags > $OUT/bench_line_$i.json 2> $OUT/bench_$i.err
     echo "[$i] $spec rc=$?" )
   python3 - "$OUT/bench_$i.json" <<'PY'
 import json,sys
 try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d=json.load(open(sys.argv[1]))
     print("  value", d["value"], "ms/step", d["ms_per_step"], {k:v["ms"] for k,v in d.get("kernels",{}).items()})
 except Exception as e:
     print("  (no json)", e)

@@ -58,9 +58,10 @@ if valu:
 stats = sorted(glob.glob(f"{src}/stats/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]   # newest run only
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
-try:
-    shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
-except FileNotFoundError:
-    pass
+for name in ("bench.json", "bench_line.json"):     # the full record and the compact line the driver parses
+    try:
+        shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
+    except FileNotFoundError:
+        pass
 for k, v in out.items():
     print(k.ljust(18), f"{v['hbm_bytes']/1e6:10.1f} MB  (fetch {v['fetch_bytes']/1e6:.1f}, write {v['write_bytes']/1e6:.1f})")
