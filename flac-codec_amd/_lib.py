@@ -140,6 +140,7 @@ def _load():
     L.flacgpu_analyze_device.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp]
     L.flacgpu_fetch.argtypes = [vp, C.POINTER(FramePlan), C.POINTER(SubframePlan), ip]
     L.flacgpu_get_stats.argtypes = [vp, C.POINTER(GpuStats)]
+    L.flacgpu_resolve.argtypes = [vp]
     L.flacgpu_device_buffer.argtypes = [vp, C.c_int]
     L.flacgpu_device_buffer.restype = vp
     L.flacgpu_set_timing.argtypes = [vp, C.c_int]

@@ -429,6 +429,9 @@ static int set_kernel_attributes_once(int device) {
 
 static int create_impl(flacgpu_ctx *c, const flacgpu_options *o);
 
+// k_layout's launches are cut into chunks of 256 tiles x 1024 frames, each with an epoch of its own, and the context hands
+// epochs out in steps of 8 (next_layout_epoch, pack.hip launch_layout): a batch can hold 8 chunks and no more
+static constexpr uint32_t kMaxBatchFrames = 8u * 256u * 1024u;
 int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, int device,
                    uint32_t max_frames, flacgpu_ctx **out) {
     if (!o || !out) return FLACGPU_ERR_INVALID_ARG;
@@ -436,7 +439,7 @@ int flacgpu_create(const flacgpu_options *o, uint32_t bps, uint32_t channels, in
     // Options validation, encode.rs:1418-1455; stream validation, :495, :1904
     if (o->block_size < 16 || o->block_size > 65535 || o->max_lpc_order > 32 ||
         o->max_partition_order > 15 || bps < 1 || bps > 32 || channels < 1 || channels > 8 ||
-        max_frames == 0 || max_frames > (1u << 24)) {
+        max_frames == 0 || max_frames > kMaxBatchFrames) {
         g_last_error = "invalid option / stream parameter";
         return FLACGPU_ERR_INVALID_ARG;
     }
@@ -782,7 +785,10 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // (6, 8 channels: k_sub64, which needs its edge records; 3, 4: k_frame64)
     // (>= 8-bit samples: the transposing buffer lies in the LDS image areas of the frame kernels, sized by the sample width)
     const uint32_t C_ = c->channels;
-    const bool xpose = split && !c->knobs.no_xpose && c->bps >= 8 && (C_ == 3 || C_ == 4 || ((C_ == 8 || C_ == 6) && c->d_edges));
+    // (the frames must then be assembled by k_frame64 / k_sub64 too -- pack_impl's f64w gates --: the generic k_emit / k_pack
+    // read the planar rows, which this path never writes)
+    const bool xpose = split && !c->knobs.no_xpose && !c->knobs.no_fused_pack && !c->knobs.no_frame64 && c->bps >= 8 &&
+                       (C_ == 3 || C_ == 4 || ((C_ == 8 || C_ == 6) && c->d_edges));
     if (split) {
         p.split_src = d_pcm;
         p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;
@@ -1785,9 +1791,9 @@ int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint
     c->packed_src = nullptr;
     if (c->knobs.upload_by_kernel && bytes_per_sample != 4) {
         c->packed_src = pcm_le;
-    } else if (c->knobs.upload_by_kernel) {
+    } else if (c->knobs.upload_by_kernel && bytes % 16 == 0) {   // (whole 16-byte pieces only: no read past the caller's buffer)
         hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(WG), 0, st, reinterpret_cast<const uint4 *>(pcm_le),
-                           reinterpret_cast<uint4 *>(c->d_in), (bytes + 15) / 16);
+                           reinterpret_cast<uint4 *>(c->d_in), bytes / 16);
     } else {
         HIP_TRY(hipMemcpyAsync(c->d_in, pcm_le, bytes, hipMemcpyHostToDevice, st));
     }
@@ -2034,6 +2040,13 @@ int flacgpu_fetch_decoded(flacgpu_ctx *c, int32_t *interleaved) {
             for (size_t ch = 0; ch < C; ch++) interleaved[o++] = planar[(f * C + ch) * ldb + i];
     }
     return FLACGPU_OK;
+}
+
+int flacgpu_resolve(flacgpu_ctx *c) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
+    if (int rc = ctx_sync(c)) return rc;
+    return resolve_order_ties(c);
 }
 
 int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {

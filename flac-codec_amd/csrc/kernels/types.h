@@ -79,7 +79,7 @@ struct Params {
     // split_dst == nullptr with several channels: nobody wants the rows -- XPOSE below
     const int32_t *split_src;
     int32_t *split_dst;
-    // XPOSE (with split_src; 4 or 8 channels): k_cand64 and k_sub64 read the interleaved batch in place as well
+    // XPOSE (with split_src; 3, 4, 6 or 8 channels): k_cand64 and k_sub64 read the interleaved batch in place as well
     // (load_lane_xpose), the planar rows are never written
     uint32_t xpose;
     const double *window_full, *window_last;

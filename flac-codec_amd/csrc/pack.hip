@@ -32,6 +32,7 @@ void launch_layout(const Params &p, const PackParams &q, hipStream_t st) {
     constexpr uint32_t kMaxTiles = 256;
     Params r = p;
     PackParams e = q;
+    // (flacgpu_create refuses max_frames beyond 8 chunks, so the epochs stay inside this call's range)
     for (uint32_t done = 0; done < p.fcount || done == 0; done += kMaxTiles * 1024u) {
         r.f0 = p.f0 + done;
         r.fcount = std::min(p.fcount - done, kMaxTiles * 1024u);

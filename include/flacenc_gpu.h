@@ -140,7 +140,8 @@ enum {
 
 /* Create a context for one stream shape.  Replaces `EncodingCaches`
  * (encode.rs:1810-1851): all scratch lives in HBM, sized for `max_frames`
- * FLAC frames per call.  device < 0 selects the current HIP device. */
+ * FLAC frames per call (at most 2 097 152: eight frame-layout chunks of 256 x 1024 frames).
+ * device < 0 selects the current HIP device. */
 int flacgpu_create(const flacgpu_options *opts, uint32_t bits_per_sample, uint32_t channels,
                    int device, uint32_t max_frames, flacgpu_ctx **out);
 void flacgpu_destroy(flacgpu_ctx *ctx);
@@ -169,7 +170,7 @@ int flacgpu_analyze(flacgpu_ctx *ctx, const int32_t *pcm, int layout, uint32_t n
  * Every entry point makes the context's device current for the duration of the call and restores
  * the caller's device afterwards.
  * Lifetime of d_pcm: interleaved stereo PCM of whole blocks of 1024, 1152, 2048, 2304 or 4096 samples (<= 24 bits), interleaved
- * 4- and 8-channel PCM of whole 4096-sample blocks (LPC order 1..16), one-channel PCM and planar PCM are read IN PLACE by the
+ * 3-, 4-, 6- and 8-channel PCM of whole 4096-sample blocks (LPC order 1..16), one-channel PCM and planar PCM are read IN PLACE by the
  * analysis and frame kernels -- the
  * context keeps no copy (no K0 split pass; this is what the reference's `write(&[i32])` hands over,
  * encode.rs:558).  The buffer must therefore stay valid and unchanged until the batch's results have
@@ -188,6 +189,14 @@ int flacgpu_get_stats(flacgpu_ctx *ctx, flacgpu_stats *out);
  * 5 frame byte offsets (uint64[n_frames + 1]), 6 the autocorrelation of every candidate (double[n_frames * candidates][36]:
  * lags 0 .. max_lpc_order of the windowed samples, encode.rs:3403-3413 -- bit for bit the reference's sums). */
 void *flacgpu_device_buffer(flacgpu_ctx *ctx, int which);
+/* The plans (0, 1) and the frame bytes / offsets (4, 5) an asynchronous call leaves in HBM are FINAL only after a resolving
+ * entry point has run: flacgpu_fetch, flacgpu_fetch_frames, flacgpu_frames_ready, flacgpu_verify_device -- or this one, for
+ * callers that consume the device buffers directly.  It waits for the context's stream, re-decides on the host the few
+ * candidates whose LPC order estimate lies inside the libm-sensitive band (encode.rs:3656-3702) and re-runs the candidate
+ * stage with the exact ResidualOverflow test (encode.rs:3189-3201) when the unchecked FIR could not rule an overflow out
+ * (flacgpu_stats::fir_recheck != 0), then re-assembles the frames.  Nothing to do (the usual case): one stream sync and a
+ * 16-byte read.  Synchronous. */
+int flacgpu_resolve(flacgpu_ctx *ctx);
 
 /* ---- device-side frame assembly ---------------------------------
  * Replaces, for the frames of the last flacgpu_analyze_device call, the host half of

@@ -201,6 +201,29 @@ def test_generic_kernels_at_wave_block_lengths(monkeypatch):
     run_case(synth_fast(602, 2, 24, 4096 * 3), 2, 24, max_lpc=32)
 
 
+@pytest.mark.parametrize("knob", ["FLACGPU_NO_FRAME64", "FLACGPU_NO_FUSED_PACK"])
+@pytest.mark.parametrize("channels", [3, 4, 6, 8])
+def test_generic_packer_alone_on_multichannel_input(monkeypatch, knob, channels):
+    """with the wave frame kernels switched off ALONE, 3/4/6/8 interleaved channels must not take the
+    in-place (XPOSE) analysis -- the generic k_emit / k_pack read the planar rows, which that path never writes."""
+    monkeypatch.setenv(knob, "1")
+    run_case(synth_fast(610 + channels, channels, 24, 4096 * 3), channels, 24, rate=96000)
+
+
+def test_resolve_entry_point_is_idempotent():
+    """flacgpu_resolve: the explicit 'make the device buffers final' call for consumers of flacgpu_device_buffer."""
+    from flac_codec_amd import _lib
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    pcm = synth_fast(620, 2, 24, 4096 * 4)
+    an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=4)
+    want, off = an.encode_frames(pcm, 4, 4096, 0, 48000)
+    assert _lib.lib().flacgpu_resolve(an._h) == 0 and _lib.lib().flacgpu_resolve(an._h) == 0
+    got, off2 = an.fetch_frames(4)
+    an.close()
+    assert got == want and off == off2
+
+
 def test_more_than_8192_frames_in_one_batch():
     """k_layout gives each of its 1024 lanes a run of frames; above 8192 frames the runs are longer
     than its register path (9 frames per lane here).  Spot frames against the oracle, everything
