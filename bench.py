@@ -916,6 +916,110 @@ def metric_text(cfg, bit_exact):
     return f"Msamples/s encode at {what}" + ("; bit-exact vs reference" if bit_exact else "; NOT bit-exact (experiment)")
 
 
+def in_process(args):
+    """--in-process: ONE process drives all N devices through the C ABI's flacgpu_multi_* (include/flacenc_gpu.h "several
+    GPUs": a shard -- contexts in rotation, own HIP streams -- per device, contiguous frame ranges, the four-integer
+    records merged on the host); no torch.distributed, no RCCL: the path has no data exchange.  Same contract as the
+    one-process-per-GPU run: W warm-up steps, K timed steps bracketed by a sync of every device, whole-job throughput."""
+    import torch
+
+    import _oracle as orc
+    from _compare import orc_options_for
+    from flac_codec_amd.gpu import MultiDevice
+
+    N = args.gpus
+    share = os.environ.get("FLAC_BENCH_SHARE_DEVICE") == "1"   # TEST: every shard on GPU 0
+    if not share and torch.cuda.device_count() < N:
+        sys.stderr.write(f"bench.py: --gpus {N} but only {torch.cuda.device_count()} visible; refusing to report\n")
+        sys.exit(3)
+    devices = [0] * N if share else list(range(N))
+    cfg = CONFIGS[args.config]
+    C, BPS, RATE = cfg["ch"], cfg["bps"], cfg["rate"]
+    F, ctxs = args.frames, args.contexts
+    md = MultiDevice(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, BPS, C, max_frames=F, devices=devices, depth=ctxs)
+    pcm = [[make_pcm(1000 + 16 * args.config + 101 * ((i + k) % ctxs), F, C, BPS, args.signal,
+                     HI_SECTIONS.get(args.config, 6)) for i in range(ctxs)] for k in range(N)]
+    bufs = [[torch.from_numpy(p).to(f"cuda:{devices[k]}") for p in pcm[k]] for k in range(N)]
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    n = [0]
+
+    def step():   # shard k encodes frames [k F, (k + 1) F) of the job: contiguous ranges per device
+        i = n[0] % ctxs
+        n[0] += 1
+        for k in range(N):
+            md.encode_device(k, bufs[k][i].data_ptr(), F, BLOCK, k * F, RATE)
+
+    sync()
+    t = time.perf_counter()
+    pre = 0
+    while (time.perf_counter() - t) * 1e3 < args.prewarm_ms:
+        for _ in range(8):
+            step()
+        md.wait()
+        pre += 8
+    for _ in range(args.warmup):
+        step()
+    md.wait()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    md.wait()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_shard, merged = md.counters()
+    # parity: every shard's last batch -- distinct frames byte for byte against the oracle
+    oopts = orc_options_for(BLOCK, cfg["po"], cfg["lpc"], True, True)
+    last = (n[0] - 1) % ctxs
+    identical = 0
+    for k in range(N):
+        data, off = md.fetch_last(k, F)
+        p = pcm[k][last]
+        for f in range(min(DISTINCT, F)):
+            planar = np.ascontiguousarray(p[f * BLOCK * C:(f + 1) * BLOCK * C].reshape(BLOCK, C).T)
+            rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, planar, frame_number=k * F + f)
+            assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"shard {k}: frame {f} differs from the oracle"
+            identical += 1
+    md.close()
+    del bufs
+    # the dominant kernel's roofline on device 0 (one context, kernels back to back), as in the per-rank run
+    w = Workload(torch, args.config, F, 0, 1, devices[0], 0, signal=args.signal)
+    w.ans[0].encode_device(w.d_pcm[0].data_ptr(), F, BLOCK, 0, RATE, stream=w.streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    _, off0 = w.ans[0].fetch_frames(F)
+    kernels, dom, alg = w.kernels_report(off0[F])
+    traffic = traffic_src = valu = stale = None
+    if F == FRAMES:
+        traffic, traffic_src, valu, stale = profile_figures(args.config, dom, kernels[dom]["ms"], args.signal)
+    roofline = roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale)
+    w.close()
+    samples_per_step = N * F * BLOCK * C
+    ms = elapsed / args.steps * 1e3
+    out = {
+        "metric": metric_text(args.config, True), "value": round(samples_per_step * args.steps / elapsed / 1e6, 2),
+        "unit": "Msamples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32/i64 (+f64 LPC analysis)",
+        "data": "synthetic",
+        "config": {"workload": f"config {args.config}: {cfg['text']}; {F} frames per GPU per step, PCM resident in HBM, "
+                               f"ONE process driving {N} device shard(s) through flacgpu_multi_* ({ctxs} contexts each)",
+                   "baseline_config": args.config, "level": cfg["level"], "frames_per_gpu": F, "frames_per_step": N * F,
+                   "parallelism": f"frame ranges x{N}, in-process", "contexts": ctxs, "devices": devices,
+                   "prewarm": f"{pre} untimed steps"},
+        "roofline": roofline, "cpu_baseline": None, "kernels": kernels, "build_id": running_build_id(),
+        "hbm_bound_fraction": round((8.0 * samples_per_step / N) / (ms * 1e-3) / 8e12, 4),
+        "parity": {"frames_byte_identical_to_oracle_per_rank": identical // N, "frames_checked_per_rank": identical // N,
+                   "ranks_checked": N},
+        "shard_counters": {"total_frames": merged[0], "total_bytes": merged[1], "min_frame": merged[2],
+                           "max_frame": merged[3], "frames_per_rank": [c[0] for c in per_shard], "ranks_seen": N,
+                           "backend": "in-process (flacgpu_merge_counters)"},
+    }
+    print(final_line(out, write_detail(out, args.detail)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -959,8 +1063,13 @@ def main():
                          "else bench_detail.json beside bench.py); stdout carries ONE compact line")
     ap.add_argument("--sustained-steps", type=int, default=200,
                     help="steps of the additional long timed loop reported as `sustained`")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process drives all --gpus devices through the C ABI's flacgpu_multi_* (no torch.distributed); "
+                         "default: one process per GPU")
     args = ap.parse_args()
 
+    if args.in_process:
+        return in_process(args)
     if args.experiment == "mfma_autocorr":
         os.environ["FLACGPU_TEST_KNOBS"] = "1"            # test-only knobs are ignored without this
         os.environ["FLACGPU_EXPERIMENT_MFMA_AC"] = "1"   # read by the library when a context is created

@@ -87,6 +87,14 @@ class StreamInfo(C.Structure):
     ]
 
 
+class ShardCounters(C.Structure):
+    """flacgpu_shard_counters: the four integers that cross shards of a stream (include/flacenc_gpu.h)."""
+    _fields_ = [("frames", C.c_uint64), ("bytes", C.c_uint64), ("min_frame", C.c_uint64), ("max_frame", C.c_uint64)]
+
+    def as_list(self):
+        return [int(self.frames), int(self.bytes), int(self.min_frame), int(self.max_frame)]
+
+
 class GpuStats(C.Structure):
     _fields_ = [
         ("frames", C.c_uint32),
@@ -191,6 +199,29 @@ def _load():
     L.flacgpu_pipeline_depth.argtypes = [vp]
     L.flacgpu_pipeline_depth.restype = C.c_uint32
     L.flacgpu_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    sc = C.POINTER(ShardCounters)
+    u64p = C.POINTER(C.c_uint64)
+    L.flacgpu_merge_counters.argtypes = [sc, C.c_uint32, sc, u64p]
+    L.flacgpu_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]
+    L.flacgpu_shard_range.restype = None
+    L.flacgpu_device_count.argtypes = []
+    L.flacgpu_multi_create.argtypes = [C.POINTER(GpuOptions), C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.flacgpu_multi_destroy.argtypes = [vp]
+    L.flacgpu_multi_destroy.restype = None
+    L.flacgpu_multi_shards.argtypes = [vp]
+    L.flacgpu_multi_shards.restype = C.c_uint32
+    L.flacgpu_multi_device_of.argtypes = [vp, C.c_uint32]
+    L.flacgpu_multi_encode.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                       C.c_void_p, C.c_size_t, u64p, u64p, sc, sc]
+    L.flacgpu_multi_encode_device.argtypes = [vp, C.c_uint32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    L.flacgpu_multi_wait.argtypes = [vp]
+    L.flacgpu_multi_counters.argtypes = [vp, sc, sc]
+    L.flacgpu_multi_last_context.argtypes = [vp, C.c_uint32]
+    L.flacgpu_multi_last_context.restype = vp
+    L.flacgpu_rccl_available.argtypes = []
+    L.flacgpu_rccl_allgather_counters.argtypes = [vp, vp, sc, sc, C.c_uint32, C.POINTER(C.c_uint32),
+                                                  C.POINTER(C.c_uint32)]
     L.flacgpu_build_id.argtypes = []
     L.flacgpu_build_id.restype = C.c_char_p
     return L

@@ -1737,6 +1737,10 @@ int flacgpu_current_device(void) {
     int d = -1;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
 }
+int flacgpu_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_sample) {
     return c && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample) ? 1 : 0;
 }

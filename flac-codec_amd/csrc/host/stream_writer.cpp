@@ -1306,8 +1306,25 @@ size_t flacenc_worst_case_bytes(const flacenc_options *opts, uint32_t bits_per_s
 }
 
 int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
+    return flacenc_encode_many_devices(opts_in, jobs, n_jobs, threads, nullptr, 0);
+}
+
+// The same front end over SEVERAL devices: streams are independent (the natural shard -- no cross-stream state at all in
+// the reference: one Encoder per file, encode.rs:1882-1980), so stream i goes whole to devices[i mod n_devices]; the
+// pooled analysis lanes are keyed by device, the host workers and the MD5 engines are shared.
+int flacenc_encode_many_devices(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads,
+                                const int *devices, uint32_t n_devices) {
     if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
     if (int e = options_error(*opts_in)) return e;
+    std::vector<int> devs;
+    if (devices && n_devices) {
+        devs.assign(devices, devices + n_devices);
+    } else if (n_devices == FLACENC_ALL_DEVICES) {
+        for (int d = 0, n = flacgpu_device_count(); d < n; d++) devs.push_back(d);
+        if (devs.empty()) return FLACENC_ERR_GPU;
+    }
+    for (int d : devs)
+        if (d < 0 || d >= flacgpu_device_count()) return FLACENC_ERR_INVALID_ARG;
     // several streams at a time: their MD5 chains share the multi-stream engines (one AVX-512 lane each)
     flacenc_options shared = *opts_in;
     if (threads >= 3 && n_jobs >= 3) {
@@ -1347,7 +1364,9 @@ int flacenc_encode_many(const flacenc_options *opts_in, flacenc_job *jobs, size_
         std::unique_ptr<flacenc_writer> w(new flacenc_writer());
         w->kind = flacenc_writer::SAMPLE;
         w->use_fixed_sink(j.out, j.out_cap);
-        int rc = w->init(*opts, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
+        flacenc_options mine = *opts;
+        if (!devs.empty()) mine.device = devs[i % devs.size()];
+        int rc = w->init(mine, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
         const size_t head = kPrime * static_cast<size_t>(opts->block_size) * j.channels;
         if (!rc && opts->shared_md5 && j.count >= 2 * head) {
             rc = w->write_direct(j.samples, head);

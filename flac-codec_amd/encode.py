@@ -184,6 +184,8 @@ def _stream_lib():
         L.flacenc_stream_writer_free.restype = None
         L.flacenc_last_error.restype = C.c_char_p
         L.flacenc_encode_many.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32]
+        L.flacenc_encode_many_devices.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32, C.POINTER(C.c_int),
+                                                  C.c_uint32]
         _bound = True
     return L
 
@@ -562,8 +564,10 @@ class BatchEncoder:
     workers busy, each running FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) for
     one stream at a time; output buffers are allocated once and reused by later calls."""
 
-    def __init__(self, options, threads=0):
-        self._opts, self._threads = options, threads
+    def __init__(self, options, threads=0, devices=None):
+        """devices: None (the options' device), "all" (every visible device) or a list of HIP ordinals -- stream i is
+        encoded whole on devices[i mod len] (flacenc_encode_many_devices)."""
+        self._opts, self._threads, self._devices = options, threads, devices
         self._bufs = []
 
     def encode(self, streams, sample_rate, bits_per_sample, channels, copy=True):
@@ -588,7 +592,15 @@ class BatchEncoder:
             j.sample_rate, j.bits_per_sample, j.channels = sample_rate, bits_per_sample, channels
             j.out = self._bufs[i].ctypes.data
             j.out_cap = self._bufs[i].size
-        _check(L.flacenc_encode_many(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+        if self._devices is None:
+            _check(L.flacenc_encode_many(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+        elif self._devices == "all":
+            _check(L.flacenc_encode_many_devices(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads, None,
+                                                 0xFFFFFFFF))
+        else:
+            devs = (C.c_int * len(self._devices))(*self._devices)
+            _check(L.flacenc_encode_many_devices(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads, devs,
+                                                 len(self._devices)))
         self.last_jobs = [{k: getattr(jobs[i], k) for k in ("elapsed_ms", "pack_ms", "gpu_ms", "md5_ms", "start_ms")}
                           for i in range(len(arrs))]
         views = [self._bufs[i][: jobs[i].out_len] for i in range(len(arrs))]

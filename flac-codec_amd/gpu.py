@@ -395,3 +395,118 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+
+def merge_counters_c(per_shard):
+    """flacgpu_merge_counters on [[frames, bytes, min_frame, max_frame], ...]: (merged record, shard byte offsets)."""
+    n = len(per_shard)
+    arr = (_lib.ShardCounters * n)(*[_lib.ShardCounters(*[int(v) for v in c]) for c in per_shard])
+    merged = _lib.ShardCounters()
+    offs = (C.c_uint64 * n)()
+    rc = _lib.lib().flacgpu_merge_counters(arr, n, C.byref(merged), offs)
+    if rc:
+        raise GpuError(rc, "flacgpu_merge_counters")
+    return merged.as_list(), [int(v) for v in offs]
+
+
+def shard_range_c(total_frames, shards, shard):
+    lo, hi = C.c_uint64(0), C.c_uint64(0)
+    _lib.lib().flacgpu_shard_range(total_frames, shards, shard, C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+class MultiDevice:
+    """flacgpu_multi_* (include/flacenc_gpu.h "several GPUs"): one process, one shard per listed device, contiguous frame
+    ranges of one stream per shard, the four-integer records merged on the host.  `devices=None`: every visible device;
+    an ordinal may be listed more than once (a 1-GPU box then exercises the whole multi-shard path)."""
+
+    def __init__(self, block_size, max_partition_order, max_lpc_order, mid_side, exhaustive, window_kind, window_param,
+                 bits_per_sample, channels, max_frames, devices=None, depth=2):
+        L = _lib.lib()
+        o = GpuOptions(block_size, max_partition_order, max_lpc_order or 0, int(bool(mid_side)),
+                       int(bool(exhaustive)), window_kind, 0, window_param)
+        self._h = C.c_void_p(None)
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        rc = L.flacgpu_multi_create(C.byref(o), bits_per_sample, channels, devs, len(devices) if devices else 0,
+                                    max_frames, depth, C.byref(self._h))
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_create")
+        self.shards = L.flacgpu_multi_shards(self._h)
+        self.devices = [L.flacgpu_multi_device_of(self._h, k) for k in range(self.shards)]
+        self.block_size, self.channels, self.bits_per_sample = block_size, channels, bits_per_sample
+
+    def encode(self, pcm, n_frames, last_frame_len, first_frame_number, sample_rate, bytes_per_sample=4):
+        """Host PCM of one stream's run of blocks (int32 array, or a uint8 array of packed little-endian samples) ->
+        (frame bytes, offsets[n_frames + 1], per-shard records, merged record)."""
+        L = _lib.lib()
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32 if bytes_per_sample == 4 else np.uint8)
+        off = (C.c_uint64 * (n_frames + 1))()
+        total = C.c_uint64(0)
+        per = (_lib.ShardCounters * self.shards)()
+        merged = _lib.ShardCounters()
+        args = (self._h, C.c_void_p(pcm.ctypes.data), bytes_per_sample, n_frames, last_frame_len, first_frame_number,
+                sample_rate)
+        cap = n_frames * (self.block_size * self.channels * ((self.bits_per_sample + 7) // 8 + 1) + 64)
+        buf = np.empty(cap, dtype=np.uint8)
+        rc = L.flacgpu_multi_encode(*args, C.c_void_p(buf.ctypes.data), cap, off, C.byref(total), per, C.byref(merged))
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_encode")
+        return (buf[: total.value].tobytes(), [int(v) for v in off], [c.as_list() for c in per], merged.as_list())
+
+    def encode_device(self, shard, device_ptr, n_frames, last_frame_len, first_frame_number, sample_rate,
+                      layout=LAYOUT_INTERLEAVED):
+        rc = _lib.lib().flacgpu_multi_encode_device(self._h, shard, C.c_void_p(device_ptr), layout, n_frames,
+                                                    last_frame_len, first_frame_number, sample_rate)
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_encode_device")
+
+    def wait(self):
+        rc = _lib.lib().flacgpu_multi_wait(self._h)
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_wait")
+
+    def counters(self):
+        per = (_lib.ShardCounters * self.shards)()
+        merged = _lib.ShardCounters()
+        rc = _lib.lib().flacgpu_multi_counters(self._h, per, C.byref(merged))
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_counters")
+        return [c.as_list() for c in per], merged.as_list()
+
+    def fetch_last(self, shard, n_frames):
+        """Frame bytes and offsets of shard `shard`'s last resident batch."""
+        h = _lib.lib().flacgpu_multi_last_context(self._h, shard)
+        off = (C.c_uint64 * (n_frames + 1))()
+        total = C.c_uint64(0)
+        rc = _lib.lib().flacgpu_fetch_frames(C.c_void_p(h), None, 0, off, C.byref(total))
+        if rc not in (0, -5):
+            raise GpuError(rc, "flacgpu_fetch_frames")
+        buf = np.empty(total.value, dtype=np.uint8)
+        rc = _lib.lib().flacgpu_fetch_frames(C.c_void_p(h), C.c_void_p(buf.ctypes.data), buf.size, off, C.byref(total))
+        if rc:
+            raise GpuError(rc, "flacgpu_fetch_frames")
+        return buf.tobytes(), [int(v) for v in off]
+
+    def close(self):
+        if self._h:
+            _lib.lib().flacgpu_multi_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rccl_allgather_counters(nccl_comm, local, cap_ranks=64, stream=None):
+    """flacgpu_rccl_allgather_counters: every rank's [frames, bytes, min_frame, max_frame] over the caller's RCCL
+    communicator (an ncclComm_t as an integer / c_void_p); returns (records in rank order, this rank)."""
+    mine = _lib.ShardCounters(*[int(v) for v in local])
+    out = (_lib.ShardCounters * cap_ranks)()
+    n, me = C.c_uint32(0), C.c_uint32(0)
+    rc = _lib.lib().flacgpu_rccl_allgather_counters(C.c_void_p(nccl_comm), C.c_void_p(stream or 0), C.byref(mine), out,
+                                                    cap_ranks, C.byref(n), C.byref(me))
+    if rc:
+        raise GpuError(rc, "flacgpu_rccl_allgather_counters")
+    return [out[i].as_list() for i in range(n.value)], int(me.value)

@@ -154,6 +154,72 @@ def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, 
     return finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sample, channels, dist)
 
 
+def encode_stream_multi_device(pcm, options, sample_rate, bits_per_sample, channels, devices=None, batch_frames=1024,
+                               depth=2):
+    """ONE stream, ONE process, several GPUs (flacgpu_multi_*, include/flacenc_gpu.h): the C ABI cuts the stream's
+    blocks into contiguous frame ranges, one per listed device (`devices=None`: all visible; an ordinal may repeat),
+    merges the four-integer records and hands the frames back in stream order; the owner adds the MD5 and the metadata
+    (flacenc_stream_header).  Returns (.flac bytes, per-shard records, merged record) -- the bytes a single
+    FlacSampleWriter produces."""
+    import numpy as np
+
+    from .gpu import MultiDevice
+
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    co = options._c_options()
+    B, C = co.block_size, channels
+    total_pcm = pcm.size // C
+    if pcm.size % C or total_pcm == 0:
+        raise ValueError("samples not divisible by channels")
+    n_frames = (total_pcm + B - 1) // B
+    last_len = total_pcm - (n_frames - 1) * B
+    md = MultiDevice(B, co.max_partition_order, co.max_lpc_order, co.mid_side, co.exhaustive_channel_correlation,
+                     co.window_kind, co.window_param, bits_per_sample, C, max_frames=min(batch_frames, n_frames),
+                     devices=devices, depth=depth)
+    try:
+        body, off, per_shard, merged = md.encode(pcm, n_frames, last_len, 0, sample_rate)
+    finally:
+        md.close()
+    sizes = [off[i + 1] - off[i] for i in range(n_frames)]
+    assert merged == [n_frames, len(body), min(sizes), max(sizes)]
+    return _with_header(body, sizes, pcm, options, sample_rate, bits_per_sample, channels), per_shard, merged
+
+
+def _with_header(body, all_sizes, pcm, options, sample_rate, bits_per_sample, channels):
+    """Owner's half: the stream MD5 and everything in front of the first frame (flacenc_stream_header)."""
+    import hashlib
+
+    import numpy as np
+
+    from . import encode as E
+
+    co = options._c_options()
+    B, C = co.block_size, channels
+    total_pcm = pcm.size // C
+    n_frames = (total_pcm + B - 1) // B
+    last_len = total_pcm - (n_frames - 1) * B
+    width = (bits_per_sample + 7) // 8
+    le = np.ascontiguousarray(pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width])
+    md5 = hashlib.md5(le.tobytes()).digest()
+    L = E._stream_lib()
+    L.flacenc_stream_header.argtypes = [C_.POINTER(E._COptions), C_.c_uint32, C_.c_uint32, C_.c_uint32, C_.c_uint64,
+                                        C_.c_char_p, C_.c_uint64, C_.POINTER(C_.c_uint32), C_.c_uint32, C_.c_void_p,
+                                        C_.c_size_t, C_.POINTER(C_.c_size_t)]
+    fs = (C_.c_uint32 * n_frames)(*all_sizes)
+    ln = C_.c_size_t(0)
+    cap = 1 << 20
+    buf = (C_.c_uint8 * cap)()
+    rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs, last_len,
+                                 buf, cap, C_.byref(ln))
+    if rc and ln.value > cap:
+        cap = ln.value
+        buf = (C_.c_uint8 * cap)()
+        rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs,
+                                     last_len, buf, cap, C_.byref(ln))
+    E._check(rc)
+    return bytes(buf[: ln.value]) + body
+
+
 def finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sample, channels, dist=None):
     """The exchange + assembly half of `encode_stream_sharded`: every rank passes the finished frame bytes of ITS
     contiguous frame range (`mine`, with the per-frame `sizes`), rank 0 -- which owns the whole input `pcm` --
@@ -194,24 +260,4 @@ def finish_sharded_stream(mine, sizes, pcm, options, sample_rate, bits_per_sampl
     n_frames = (total_pcm + B - 1) // B
     last_len = total_pcm - (n_frames - 1) * B
     assert len(all_sizes) == n_frames and sum(all_sizes) == len(body) == merged["total_bytes"]
-    # the owner: MD5 over the little-endian ceil(bps/8)-byte samples of the whole stream
-    width = (bits_per_sample + 7) // 8
-    le = np.ascontiguousarray(pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width])
-    md5 = hashlib.md5(le.tobytes()).digest()
-    L = E._stream_lib()
-    L.flacenc_stream_header.argtypes = [C_.POINTER(E._COptions), C_.c_uint32, C_.c_uint32, C_.c_uint32, C_.c_uint64,
-                                        C_.c_char_p, C_.c_uint64, C_.POINTER(C_.c_uint32), C_.c_uint32, C_.c_void_p,
-                                        C_.c_size_t, C_.POINTER(C_.c_size_t)]
-    fs = (C_.c_uint32 * n_frames)(*all_sizes)
-    ln = C_.c_size_t(0)
-    cap = 1 << 20
-    buf = (C_.c_uint8 * cap)()
-    rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs, last_len,
-                                 buf, cap, C_.byref(ln))
-    if rc and ln.value > cap:
-        cap = ln.value
-        buf = (C_.c_uint8 * cap)()
-        rc = L.flacenc_stream_header(C_.byref(co), sample_rate, bits_per_sample, C, total_pcm, md5, n_frames, fs,
-                                     last_len, buf, cap, C_.byref(ln))
-    E._check(rc)
-    return bytes(buf[: ln.value]) + body
+    return _with_header(body, all_sizes, pcm, options, sample_rate, bits_per_sample, channels)

@@ -49,7 +49,8 @@ enum {
     FLACGPU_ERR_HIP = -3,         /* HIP runtime failure; flacgpu_last_error() has the text */
     FLACGPU_ERR_NO_DEVICE = -4,
     FLACGPU_ERR_BUFFER_TOO_SMALL = -5,
-    FLACGPU_ERR_BUSY = -6         /* flacgpu_pipeline_submit: every slot holds a batch, retire one first */
+    FLACGPU_ERR_BUSY = -6,        /* flacgpu_pipeline_submit: every slot holds a batch, retire one first */
+    FLACGPU_ERR_NO_RCCL = -7      /* flacgpu_rccl_allgather_counters: librccl could not be loaded (no fallback) */
 };
 
 /* encode.rs:1713-1720 `Window` */
@@ -334,6 +335,66 @@ int flacgpu_pipeline_retire(flacgpu_pipeline *p, const uint8_t **frames, const u
                             uint64_t *total);
 uint32_t flacgpu_pipeline_in_flight(const flacgpu_pipeline *p);
 uint32_t flacgpu_pipeline_depth(const flacgpu_pipeline *p);
+
+/* ---- several GPUs ------------------------------------------------------------------------------------
+ * A FLAC frame depends on its own samples, the options and its frame number only (encode.rs:2284-2294), so a stream shards
+ * by CONTIGUOUS FRAME RANGES with no data-path exchange.  What crosses shards is bookkeeping -- the reference's single
+ * process keeps it in `Encoder` (encode.rs:1997-2022): the seek points' byte offsets, a prefix sum of frame sizes
+ * (:1999-2003), STREAMINFO's min / max frame size (:2414-2436) and the totals.  One record of four integers per shard
+ * carries all of it. */
+typedef struct {
+    uint64_t frames;     /* frames of the shard */
+    uint64_t bytes;      /* their bytes */
+    uint64_t min_frame;  /* smallest / largest frame of the shard; 0 for a shard without frames, which takes no part in */
+    uint64_t max_frame;  /* the merged min / max */
+} flacgpu_shard_counters;
+/* Stream-level bookkeeping from the per-shard records, in shard order: totals, min / max frame size and (optional, n
+ * entries) the byte offset of every shard's first frame behind the stream's first frame (exclusive prefix sum). */
+int flacgpu_merge_counters(const flacgpu_shard_counters *shards, uint32_t n, flacgpu_shard_counters *merged,
+                           uint64_t *shard_byte_offsets);
+/* The contiguous frame range [lo, hi) of shard `shard` of `shards`: [k F / G, (k + 1) F / G). */
+void flacgpu_shard_range(uint64_t total_frames, uint32_t shards, uint32_t shard, uint64_t *lo, uint64_t *hi);
+int flacgpu_device_count(void);   /* visible HIP devices */
+
+/* ONE PROCESS, SEVERAL DEVICES.  `devices` lists HIP ordinals, one shard each (NULL / 0: every visible device; an ordinal
+ * may be listed more than once -- each listing is a shard with contexts of its own).  Every shard owns up to `depth`
+ * encoder contexts sized for `max_frames` frames per batch.
+ *   flacgpu_multi_encode         a run of blocks of ONE stream in host memory (int32, or the little-endian ceil(bps/8)-byte
+ *                                samples of flacgpu_encode_packed_async; pinned memory keeps the uploads asynchronous):
+ *                                shard k takes frames [lo_k, hi_k) -- any count, cut into batches of <= max_frames through
+ *                                a flacgpu_pipeline on its device, one host thread per shard -- with the frame numbers the
+ *                                stream gives them; the frames come back concatenated in stream order in `out`,
+ *                                `offsets` (n_frames + 1 entries), `per_shard` (flacgpu_multi_shards entries) and `merged`
+ *                                as flacgpu_merge_counters leaves them.  Any out pointer may be NULL (FLACGPU_ERR_BUFFER_TOO_SMALL
+ *                                with *total set when `out` is too small).  Byte-identical to one context's
+ *                                flacgpu_encode_frames over the same blocks.  Synchronous.
+ *   flacgpu_multi_encode_device  PCM resident in shard `shard`'s device memory: flacgpu_encode_device on the shard's next
+ *                                context in rotation, asynchronous; flacgpu_multi_wait drains every context of every shard;
+ *                                flacgpu_multi_counters reads the records of every shard's LAST batch (and merges them);
+ *                                flacgpu_multi_last_context hands that batch's context out (fetch / verify). */
+typedef struct flacgpu_multi flacgpu_multi;
+int flacgpu_multi_create(const flacgpu_options *opts, uint32_t bits_per_sample, uint32_t channels, const int *devices,
+                         uint32_t n_devices, uint32_t max_frames, uint32_t depth, flacgpu_multi **out);
+void flacgpu_multi_destroy(flacgpu_multi *m);
+uint32_t flacgpu_multi_shards(const flacgpu_multi *m);
+int flacgpu_multi_device_of(const flacgpu_multi *m, uint32_t shard);
+int flacgpu_multi_encode(flacgpu_multi *m, const void *pcm, uint32_t bytes_per_sample, uint64_t n_frames,
+                         uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate, uint8_t *out,
+                         size_t cap, uint64_t *offsets, uint64_t *total, flacgpu_shard_counters *per_shard,
+                         flacgpu_shard_counters *merged);
+int flacgpu_multi_encode_device(flacgpu_multi *m, uint32_t shard, const int32_t *d_pcm, int layout, uint32_t n_frames,
+                                uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate);
+int flacgpu_multi_wait(flacgpu_multi *m);
+int flacgpu_multi_counters(flacgpu_multi *m, flacgpu_shard_counters *per_shard, flacgpu_shard_counters *merged);
+flacgpu_ctx *flacgpu_multi_last_context(flacgpu_multi *m, uint32_t shard);
+
+/* ONE PROCESS PER GPU (torchrun / MPI): the same record all-gathered over the caller's RCCL communicator (an
+ * `ncclComm_t`; `stream` a hipStream_t or NULL) -- the path's only collective, 32 bytes per rank.  `all` receives
+ * *n_ranks records in rank order (cap_ranks entries provided).  librccl is loaded on first use; when it cannot be,
+ * the call fails with FLACGPU_ERR_NO_RCCL -- there is no fallback.  Synchronous. */
+int flacgpu_rccl_available(void);
+int flacgpu_rccl_allgather_counters(void *nccl_comm, void *stream, const flacgpu_shard_counters *mine,
+                                    flacgpu_shard_counters *all, uint32_t cap_ranks, uint32_t *n_ranks, uint32_t *my_rank);
 
 /* ---- device-side decode + verify of the frames packed last ----------
  * The reference's frame decoder (decode.rs:1388-1436 read_frame, 1494-1633 read_subframes,

@@ -181,6 +181,13 @@ typedef struct {
  * finish --, at most 64 streams open at a time: the thread count need not match the stream count (a few threads per
  * usable CPU are enough), every stream's MD5 chain starts at once.  Returns the first failing stream's status. */
 int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads);
+/* The same over several GPUs of one process: stream i is encoded whole on devices[i mod n_devices] (streams are independent:
+ * one `Encoder` per file in the reference, encode.rs:1882-1980 -- the natural shard; nothing crosses devices).  devices ==
+ * NULL with n_devices == FLACENC_ALL_DEVICES: every visible device; NULL / 0: opts->device as flacenc_encode_many.  An
+ * ordinal may be listed more than once.  Output is byte-identical to flacenc_encode_many's. */
+#define FLACENC_ALL_DEVICES 0xFFFFFFFFu
+int flacenc_encode_many_devices(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads,
+                                const int *devices, uint32_t n_devices);
 
 /* FlacStreamWriter (encode.rs:1050-1290): header-less subset frames, parameters per call. */
 typedef struct flacenc_stream_writer flacenc_stream_writer;
