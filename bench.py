@@ -779,6 +779,7 @@ def measure_other_config(torch, cfg_id, args, device, orc, signal="ar2"):
     assert ok, f"config {cfg_id} ({signal}): parity check failed"
     kernels, dom, alg = w.kernels_report(compressed)
     traffic, traffic_src, valu, stale = profile_figures(cfg_id, dom, kernels[dom]["ms"], signal)
+    st0 = w.ans[0].stats()
     cfg = w.cfg
     out = {"workload": cfg["text"], "level": cfg["level"], "signal": SIGNAL_TEXT[signal] if signal != "hi" else
            SIGNAL_TEXT[signal] % (2 * HI_SECTIONS.get(cfg_id, 6)),
@@ -789,6 +790,9 @@ def measure_other_config(torch, cfg_id, args, device, orc, signal="ar2"):
            "frames_round_tripped_on_device": w.F * len(w.ans),
            "oracle_decisions": histogram_summary(w, cfg_id),
            "dominant_kernel": roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale),
+           "fixed_count": {"decided_by_bound": st0.fixed_decided, "refetched": st0.fixed_refetched,
+                           "note": "candidates of context 0 since it was created whose exact FIXED bit count was put off "
+                                   "behind the LPC half (Params::defer_fixed): skipped / counted after a re-fetch"},
            "kernels": kernels,
            "compression_ratio": round(compressed / (w.F * BLOCK * w.C * ((w.BPS + 7) // 8)), 4)}
     w.close()
@@ -848,9 +852,14 @@ def compact_record(out, detail_path=None):
 
     def cfg_scalars(e):
         d = e.get("dominant_kernel") or {}
-        return {"ms_per_step": e.get("ms_per_step"), "kernel": d.get("kernel"), "kernel_ms": d.get("avg_launch_ms"),
-                "frac": d.get("frac"), "identical": e.get("frames_byte_identical_to_oracle"),
-                "checked": e.get("frames_checked")}
+        r = {"ms_per_step": e.get("ms_per_step"), "kernel": d.get("kernel"), "kernel_ms": d.get("avg_launch_ms"),
+             "frac": d.get("frac"), "identical": e.get("frames_byte_identical_to_oracle"),
+             "checked": e.get("frames_checked")}
+        fc = e.get("fixed_count") or {}
+        if fc.get("decided_by_bound") or fc.get("refetched"):
+            r["fixed_count_skipped"] = fc["decided_by_bound"]
+            r["fixed_count_refetched"] = fc["refetched"]
+        return r
 
     if var.get("high_order_input"):
         extras["high_order"] = cfg_scalars(var["high_order_input"])
@@ -1194,6 +1203,7 @@ def main():
         analysis_stats = {"lpc_failed": st.lpc_failed, "order_ties": st.order_ties,
                           "order_ties_resolved_on_host": st.order_ties_resolved, "log2_edge": st.log2_edge,
                           "fir_recheck": st.fir_recheck, "fir_rechecked": st.fir_rechecked,
+                          "fixed_count_decided_by_bound": st.fixed_decided, "fixed_count_refetched": st.fixed_refetched,
                           "candidates": (4 if C == 2 else C) * F}
         kernels, dom, alg = w.kernels_report(compressed_bytes)
         sum_kernels = sum(v["ms"] for v in kernels.values())

@@ -104,6 +104,8 @@ class GpuStats(C.Structure):
         ("order_ties_resolved", C.c_uint32),
         ("fir_recheck", C.c_uint32),
         ("fir_rechecked", C.c_uint32),
+        ("fixed_decided", C.c_uint32),
+        ("fixed_refetched", C.c_uint32),
     ]
 
 

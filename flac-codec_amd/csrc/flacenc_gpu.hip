@@ -59,6 +59,12 @@ extern "C" void flacgpu_early_download_counters(uint64_t *queued, uint64_t *with
     if (queued) *queued = g_early_downloads.load();
     if (with_remainder) *with_remainder = g_early_remainders.load();
 }
+// Params::defer_margin16 by default: the LPC estimate must undercut the FIXED bound by this many sixteenths of a bit per sample.
+// compute_best_order's estimate (encode.rs:3675: ln(err / 2n) / 2 ln 2 = log2(sigma) - 0.5) lies 2.5-2.9 bits per sample under
+// what Rice coding makes of the residual, so 3 bits defer only candidates that are then decided by the bound (measured,
+// profiles/r05_defer_fixed.json: 0.6 % of the deferred candidates of the high-order input take the re-read, none of SURVEY's
+// input defers at all; at 2 bits every candidate of SURVEY's input deferred and re-read: +11 % on the kernel)
+static constexpr uint32_t kDeferMargin16 = 48;
 Knobs read_knobs() {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
@@ -87,6 +93,10 @@ Knobs read_knobs() {
     k.cand_persist_n = on("FLACGPU_CAND_PERSIST_N");
     k.early_download = on("FLACGPU_EARLY_DOWNLOAD");
     if (const char *e = getenv("FLACGPU_CAND_GRID")) k.cand_grid = (uint32_t)atoi(e);
+    // A/B: Params::defer_fixed (0 never, 1 by the estimate, 2 whenever LPC parameters exist) and its margin in 1/16 bit per
+    // sample -- neither changes a byte of output
+    if (const char *e = getenv("FLACGPU_DEFER_FIXED")) k.defer_fixed = atoi(e);
+    if (const char *e = getenv("FLACGPU_DEFER_MARGIN16")) k.defer_margin16 = atoi(e);
     const char *t = getenv("FLACGPU_TEST_KNOBS");
     if (t && t[0] == '1') {
         k.experiment_mfma_ac = on("FLACGPU_EXPERIMENT_MFMA_AC");
@@ -494,8 +504,9 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_lpc, F * NC);
     ALLOC(c->d_finfo, F);
     ALLOC(c->d_fplan, F);
-    ALLOC(c->d_stats, 4 + F * NC);  // counters, then the per-candidate ORs: one memset per batch
+    ALLOC(c->d_stats, 4 + F * NC + 2);  // counters, then the per-candidate ORs (one memset per batch), then Params::defer_stats
     c->d_orbits = c->d_stats + 4;
+    HIP_TRY(hipMemset(c->d_stats + 4 + F * NC, 0, 2 * sizeof(uint32_t)));   // Params::defer_stats, cumulative
     // worst case: every subframe VERBATIM at 32 bits + headers
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
@@ -624,6 +635,9 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.tie_perturb = c->tie_perturb;
     p.check_fir = c->knobs.force_fir_check ? 1u : 0u;
     p.fir_suspect_bits = c->knobs.fir_suspect_bits ? c->knobs.fir_suspect_bits : 30u;
+    p.defer_fixed = c->knobs.defer_fixed >= 0 ? (uint32_t)c->knobs.defer_fixed : 1u;
+    p.defer_margin16 = c->knobs.defer_margin16 >= 0 ? (uint32_t)c->knobs.defer_margin16 : kDeferMargin16;
+    p.defer_stats = c->d_stats + 4 + (size_t)c->max_frames * c->ncand;   // behind the ORs; cumulative, zeroed at creation
 }
 
 // stream == NULL: the context's own (non-blocking) stream, ordered AFTER whatever the caller has
@@ -2066,6 +2080,10 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     out->order_ties_resolved = c->ties_resolved;
     out->fir_recheck = s[3];
     out->fir_rechecked = c->fir_rechecked;
+    uint32_t d[2];
+    if (int rc = copy_sync(c, d, c->d_stats + 4 + (size_t)c->max_frames * c->ncand, sizeof d, hipMemcpyDeviceToHost)) return rc;
+    out->fixed_decided = d[0];
+    out->fixed_refetched = d[1];
     return FLACGPU_OK;
 }
 

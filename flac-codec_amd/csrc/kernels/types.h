@@ -45,7 +45,9 @@ struct CandInfo {        // per (frame, candidate)
 struct LpcParams {       // per (frame, candidate), output of k_lpc
     int32_t status;      // 0 ok; else the reference's error (1 Insufficient, 2 NoBestOrder,
                          // 3 ZeroCoeffs, 4 NegativeShift)
-    uint8_t order, precision, shift, pad;
+    uint8_t order, precision, shift;
+    uint8_t est8;        // compute_best_order's size estimate of the chosen order in 1/8 bit per sample (1..255; 0: none --
+                         // the host's re-decision leaves none); a HINT for Params::defer_fixed, never part of a decision
     int32_t qlp[FLACGPU_MAX_LPC_ORDER];
 };
 
@@ -107,6 +109,16 @@ struct Params {
     // check_fir = 1 (resolve_order_ties), where every candidate takes the exact read-only test fir64_overflows first.
     uint32_t check_fir;
     uint32_t fir_suspect_bits;   // 30; a TEST knob lowers it so that ordinary input exercises the re-run
+    // The exact FIXED bit count (encode.rs:3898-3907 for the FIXED residual) put off until the LPC candidate's size is
+    // known (k_cand64p, direct stereo input) -- r05.  The partition search of the FIXED residual needs only the leaf sums
+    // the order statistics hold; from the same sums a LOWER BOUND of its exact size follows (per Rice partition
+    // sum (u >> k) >= ceil(2 S / 2^k) - count).  When k_lpc's size estimate of the LPC candidate (LpcParams::est8, 1/8 bit
+    // per sample) undercuts that bound by defer_margin16 / 16 bit per sample, the wave runs the LPC half first; an exact
+    // lpc_bits < bound then DECIDES encode.rs:2929-2934 for LPC without the FIXED count, otherwise the wave re-fetches its
+    // samples and counts after all.  0: never (A/B), 1: by the estimate, 2: whenever LPC parameters exist (TEST: every
+    // undecided candidate takes the re-fetch).  defer_stats: {waves that deferred, of those: re-fetched}, cumulative.
+    uint32_t defer_fixed, defer_margin16;
+    uint32_t *defer_stats;
 };
 
 
@@ -185,6 +197,8 @@ struct Knobs {
     double tie_band = 0.0, tie_perturb = 0.0;   // TEST
     uint32_t decode_lanes = 0;          // TEST: lanes per wave of the stand-alone decoder, 0: default
     uint32_t fir_suspect_bits = 0;      // TEST: Params::fir_suspect_bits, 0: default (30)
+    int defer_fixed = -1;               // FLACGPU_DEFER_FIXED: 0 / 1 / 2 (Params::defer_fixed); -1: default (1)
+    int defer_margin16 = -1;            // FLACGPU_DEFER_MARGIN16: Params::defer_margin16; -1: default
 };
 Knobs read_knobs();   // flacenc_gpu.hip
 

@@ -143,3 +143,41 @@ def test_bursts_that_make_the_predictor_run_wild(monkeypatch, bps, max_lpc, orde
     assert st.fir_rechecked == st.fir_recheck
     if (bps, max_lpc, burst) == (24, 32, 40):
         assert st.fir_recheck > 0, "this input is meant to reach the re-run"
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("max_lpc", [12, 32])
+def test_deferred_fixed_count_gives_the_same_bytes(monkeypatch, mode, max_lpc):
+    """Params::defer_fixed (r05): the exact FIXED bit count put off behind the LPC half and skipped where a lower bound of
+    the FIXED size already exceeds the exact LPC size (encode.rs:2929-2934), re-fetching the samples otherwise.  Never (0),
+    by the LPC estimate (1, the default) and whenever LPC parameters exist (2: the re-fetch path for every undecided
+    candidate) must all give the oracle's bytes; the counters show which paths ran."""
+    import ctypes as C
+
+    from _pcm import synth_fast
+    from flac_codec_amd import _lib
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    monkeypatch.setenv("FLACGPU_DEFER_FIXED", mode)
+    B, bps, n = 4096, 24, 24
+    # resonant frames (LPC wins by a wide margin: the bound decides) next to plain ones (it does not: the re-fetch)
+    hi = synth_hi(91, 2, bps, B * (n // 2), segment=B, orders=list(range(2, max_lpc + 1, 3)))
+    lo = synth_fast(92, 2, bps, B * (n // 2))
+    pcm = np.concatenate([hi, lo])
+    oopts = orc_options_for(B, 6, max_lpc, True, True)
+    an = GpuAnalyzer(B, 6, max_lpc, True, True, 2, 0.5, bps, 2, max_frames=n)
+    data, off = an.encode_frames(pcm, n, B, 11, 48000)
+    for f, planar in enumerate(planar_frames(pcm, 2, B)):
+        rc, fb, _ = orc.encode_frame(oopts, 48000, bps, planar, frame_number=11 + f)
+        assert rc == 0 and data[off[f]:off[f + 1]] == fb, f"mode {mode}: frame {f} differs from the oracle"
+    st = an.stats()
+    res, _ = an.verify_device(48000, 11)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+    an.close()
+    if mode == "0":
+        assert st.fixed_decided == 0 and st.fixed_refetched == 0
+    elif mode == "2":
+        assert st.fixed_decided > 0 and st.fixed_refetched > 0, (st.fixed_decided, st.fixed_refetched)
+        assert st.fixed_decided + st.fixed_refetched <= 4 * n
+    else:
+        assert st.fixed_decided > 0, "the estimate never chose to defer on resonant frames"
