@@ -749,6 +749,35 @@ def batch_sweep(torch, cfg_id, args, device, sizes=(256, 512, 1024, 2048, 4096, 
     full = rows[str(max(sizes))]["Msamples/s"]
     for r in rows.values():
         r["per_sample_rate_vs_8192"] = round(r["Msamples/s"] / full, 4)
+    # the same small batches COALESCED: max(sizes) / n segments of n frames each (of different streams: shuffled places of
+    # the buffer, their own frame numbers) as ONE batch through flacgpu_encode_segments_device -- what a caller with many
+    # small streams submits instead of one batch per stream
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    F, C, per = max(sizes), cfg["ch"], BLOCK * cfg["ch"]
+    d = [torch.from_numpy(make_pcm(1000 + 16 * cfg_id + 101 * i, F, C, cfg["bps"])).cuda() for i in range(args.contexts)]
+    ans = [GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, cfg["bps"], C, max_frames=F, device=device)
+           for _ in range(args.contexts)]
+    streams = [torch.cuda.Stream() for _ in ans]
+    rng = np.random.Generator(np.random.PCG64(5))
+    for n in sizes[:-1]:
+        k = F // n
+        order = rng.permutation(k)
+        segs = [[(d[i].data_ptr() + int(j) * n * per * 4, n, 1000 * int(j)) for j in order] for i in range(len(ans))]
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            steps = 24
+            for it in range(steps):
+                i = it % len(ans)
+                ans[i].encode_segments_device(segs[i], cfg["rate"], stream=streams[i].cuda_stream)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t) / steps * 1e3
+        rows[str(n)]["coalesced"] = {"segments_per_batch": k, "ms_per_batch_of_%d_frames" % F: round(ms, 4),
+                                     "Msamples/s": round(F * per / (ms * 1e-3) / 1e6, 1),
+                                     "per_sample_rate_vs_8192": round(F * per / (ms * 1e-3) / 1e6 / full, 4)}
+    for a in ans:
+        a.close()
     return rows
 
 

@@ -95,6 +95,11 @@ class ShardCounters(C.Structure):
         return [int(self.frames), int(self.bytes), int(self.min_frame), int(self.max_frame)]
 
 
+class Segment(C.Structure):
+    """flacgpu_segment: a run of whole blocks of one stream inside a batch of several (include/flacenc_gpu.h)."""
+    _fields_ = [("pcm", C.c_void_p), ("n_frames", C.c_uint32), ("reserved", C.c_uint32), ("first_frame_number", C.c_uint64)]
+
+
 class GpuStats(C.Structure):
     _fields_ = [
         ("frames", C.c_uint32),
@@ -201,6 +206,9 @@ def _load():
     L.flacgpu_pipeline_depth.argtypes = [vp]
     L.flacgpu_pipeline_depth.restype = C.c_uint32
     L.flacgpu_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.flacgpu_encode_segments_device.argtypes = [vp, C.POINTER(Segment), C.c_uint32, C.c_uint32, vp]
+    L.flacgpu_encode_segments.argtypes = [vp, C.POINTER(Segment), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     sc = C.POINTER(ShardCounters)
     u64p = C.POINTER(C.c_uint64)
     L.flacgpu_merge_counters.argtypes = [sc, C.c_uint32, sc, u64p]

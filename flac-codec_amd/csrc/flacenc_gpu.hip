@@ -139,6 +139,14 @@ struct flacgpu_ctx {
     double tie_band = 1e-9, tie_perturb = 0.0;
     Knobs knobs;                  // the FLACGPU_* environment, read once at flacgpu_create
     const uint8_t *packed_src = nullptr;   // upload by kernel (Knobs::upload_by_kernel): K0 reads the caller's pinned PCM itself
+    // a batch made of SEGMENTS (flacgpu_encode_segments*): per-frame frame numbers and PCM addresses on the device, their
+    // pinned staging copy, and the segments themselves (ensure_planar walks them)
+    uint64_t *d_seg_fn = nullptr, *h_seg = nullptr;
+    const int32_t **d_seg_ptr = nullptr;
+    std::vector<flacgpu_segment> segs;
+    bool seg_pending = false;   // the next analyze_impl belongs to a segments call
+    bool seg_active = false;    // the batch in hand is made of segments (frame numbers from d_seg_fn)
+    bool seg_direct = false;    // ... read in place (Params::inter_tab)
     bool env_no_direct = false;     // FLACGPU_NO_DIRECT as read at creation; copy_input: FLACGPU_TUNE_COPY_INPUT.  knobs.no_direct
     bool copy_input = false;        //   is their OR
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
@@ -563,6 +571,9 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_tile_sync);
+    if (c->d_seg_fn) (void)hipFree(c->d_seg_fn);
+    if (c->d_seg_ptr) (void)hipFree(c->d_seg_ptr);
+    if (c->h_seg) (void)hipHostFree(c->h_seg);
     (void)hipFree(c->d_edges);
     (void)hipFree(c->d_decoded); (void)hipFree(c->d_verify); (void)hipFree(c->d_big);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -694,6 +705,15 @@ static int ensure_planar(flacgpu_ctx *c) {
     if (c->planar_valid) return FLACGPU_OK;
     if (!c->direct_src || c->last_frames == 0) return FLACGPU_OK;
     if (int rc = ctx_sync(c)) return rc;
+    if (c->seg_active && c->seg_direct) {   // frame f0 + i of segment s is frame i of its own buffer
+        uint32_t f0 = 0;
+        const size_t frame_ints = (size_t)c->opts.block_size * c->channels;
+        for (const flacgpu_segment &g : c->segs) {
+            (void)launch_k0(c, g.pcm - (ptrdiff_t)(f0 * frame_ints), FLACGPU_LAYOUT_INTERLEAVED, c->last_frames, c->last_len, f0,
+                            g.n_frames, ctx_stream(c));
+            f0 += g.n_frames;
+        }
+    } else
     (void)launch_k0(c, c->direct_src, FLACGPU_LAYOUT_INTERLEAVED, c->last_frames, c->last_len, 0, c->last_frames,
                     ctx_stream(c));
     HIP_TRY(hipGetLastError());
@@ -723,6 +743,11 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         last_len > c->opts.block_size || (layout != 0 && layout != 1)) {
         g_last_error = "invalid analyze arguments";
         return FLACGPU_ERR_INVALID_ARG;
+    }
+    // (every batch passes here: one made of segments announces itself just before)
+    if (c->rng_cnt == 0 || c->rng_f0 == 0) {
+        c->seg_active = c->seg_pending;
+        c->seg_pending = false;
     }
     const uint32_t B = c->opts.block_size;
     // the reference collects partitions into ArrayVec<_, 64> and panics beyond (encode.rs:3880)
@@ -774,6 +799,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->planar_valid = !direct;
     c->direct_src = direct ? d_pcm : nullptr;
     if (direct) p.inter = d_pcm;
+    if (direct && c->seg_active && c->seg_direct) p.inter_tab = c->d_seg_ptr;   // (frames found through the table; d_pcm = the first segment)
     c->abs_valid = false;
     if (c->d_abs && first_range) HIP_TRY(hipMemsetAsync(c->d_abs, 0, sizeof(unsigned long long) * 4 * n_frames, st));
     // K0 (+ OR of every candidate's samples -> wasted bits)
@@ -1096,6 +1122,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     const Params &p = c->last_params;
     PackParams q;
     q.first_frame_number = first_frame_number;
+    if (c->seg_active) q.frame_numbers = c->d_seg_fn;
     q.sample_rate = sample_rate;
     q.out_words = c->d_packed;   // (k_layout does not look at it; replaced below for host output)
     q.frame_off = c->d_frame_off;
@@ -1345,6 +1372,79 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     c->last_first_frame = first_frame_number;
     c->last_rate = sample_rate;
     return FLACGPU_OK;
+}
+
+// ---- a batch made of SEGMENTS: runs of whole blocks of several streams of the context's shape analysed and assembled as ONE
+// batch (the kernels' launches and their serial walk over a block are paid once, not once per stream).  Frame f of the batch
+// is frame f - f0(s) of its segment s; its frame number and, for direct stereo input read in place, its address come from
+// per-frame tables (PackParams::frame_numbers, Params::inter_tab).
+static int segments_common(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t n_segs, bool on_device, uint32_t sample_rate,
+                           hipStream_t st) {
+    const uint32_t B = c->opts.block_size;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_segs; i++) {
+        if (!segs[i].pcm || segs[i].n_frames == 0) {
+            g_last_error = "flacgpu_encode_segments: an empty segment";
+            return FLACGPU_ERR_INVALID_ARG;
+        }
+        total += segs[i].n_frames;
+    }
+    if (total == 0 || total > c->max_frames) {
+        g_last_error = "flacgpu_encode_segments: more frames than the context was created for";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    const size_t F = c->max_frames;
+    if (!c->d_seg_fn) {
+        HIP_TRY(hipMalloc((void **)&c->d_seg_fn, sizeof(uint64_t) * F));
+        HIP_TRY(hipMalloc((void **)&c->d_seg_ptr, sizeof(int32_t *) * F));
+        HIP_TRY(hipHostMalloc((void **)&c->h_seg, sizeof(uint64_t) * 2 * F, hipHostMallocDefault));
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // (the staging arrays of the batch before are free)
+    const size_t frame_ints = (size_t)B * c->channels;
+    Params probe;
+    fill_params(c, (uint32_t)total, B, probe);
+    bool direct = on_device && direct_input_ok(c, probe, B);
+    for (uint32_t i = 0; i < n_segs && direct; i++) direct = ((uintptr_t)segs[i].pcm & 15u) == 0;
+    uint64_t *fn = c->h_seg;
+    const int32_t **ptr = reinterpret_cast<const int32_t **>(c->h_seg + F);
+    uint32_t f = 0;
+    c->segs.assign(segs, segs + n_segs);
+    for (uint32_t i = 0; i < n_segs; i++) {
+        for (uint32_t k = 0; k < segs[i].n_frames; k++, f++) {
+            fn[f] = segs[i].first_frame_number + k;
+            ptr[f] = segs[i].pcm + (size_t)k * frame_ints;
+        }
+        if (!direct)   // gathered into the context's input buffer (host segments: the upload itself)
+            HIP_TRY(hipMemcpyAsync(c->d_in + (size_t)(f - segs[i].n_frames) * frame_ints, segs[i].pcm,
+                                   sizeof(int32_t) * frame_ints * segs[i].n_frames,
+                                   on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_seg_fn, fn, sizeof(uint64_t) * total, hipMemcpyHostToDevice, st));
+    if (direct) HIP_TRY(hipMemcpyAsync(c->d_seg_ptr, ptr, sizeof(int32_t *) * total, hipMemcpyHostToDevice, st));
+    c->seg_pending = true;
+    c->seg_direct = direct;
+    c->rng_f0 = c->rng_cnt = 0;
+    if (int rc = analyze_impl(c, direct ? segs[0].pcm : c->d_in, FLACGPU_LAYOUT_INTERLEAVED, (uint32_t)total, B, st, 0)) return rc;
+    return pack_impl(c, segs[0].first_frame_number, sample_rate, st, nullptr);
+}
+
+int flacgpu_encode_segments_device(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t n_segs, uint32_t sample_rate,
+                                   void *stream) {
+    if (!c || !segs || n_segs == 0) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
+    hipStream_t st;
+    if (int rc = resolve_stream(c, stream, &st)) return rc;
+    return segments_common(c, segs, n_segs, true, sample_rate, st);
+}
+
+int flacgpu_encode_segments(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t n_segs, uint32_t sample_rate, uint8_t *out,
+                            size_t cap, uint64_t *offsets, uint64_t *total) {
+    if (!c || !segs || n_segs == 0) return FLACGPU_ERR_INVALID_ARG;
+    {
+        CTX_GUARD(c);
+        if (int rc = segments_common(c, segs, n_segs, false, sample_rate, c->own_stream)) return rc;
+    }
+    return flacgpu_fetch_frames(c, out, cap, offsets, total);
 }
 
 int flacgpu_fetch_frames(flacgpu_ctx *c, uint8_t *out, size_t cap, uint64_t *offsets,
@@ -1996,6 +2096,7 @@ int flacgpu_verify_device(flacgpu_ctx *c, uint32_t sample_rate, uint64_t first_f
     }
     PackParams q;
     q.first_frame_number = first_frame_number;
+    if (c->seg_active) q.frame_numbers = c->d_seg_fn;
     q.sample_rate = sample_rate;
     q.out_words = c->d_packed;
     q.frame_off = c->d_frame_off;

@@ -76,6 +76,9 @@ struct Params {
     // samples) read by k_autocorr4 / k_cand64p / k_frame64 themselves -- no K0 split, `planar` is not
     // written.  nullptr: the kernels read `planar`
     const int32_t *inter;
+    // ... or, a batch made of SEGMENTS (runs of whole blocks of several streams, flacgpu_encode_segments_device): the
+    // address of every frame's PCM, [n_frames]; nullptr: frame f starts at inter + f * 2 * block_size (inter_frame below)
+    const int32_t *const *inter_tab;
     // SPLIT input: a batch of interleaved INDEPENDENT channels ([frame][sample][channel]) that k_autocorr4's producers
     // split into the planar rows (split_dst = `planar`) while they read it -- no k_deinterleave_n pass; nullptr: not used
     // split_dst == nullptr with several channels: nobody wants the rows -- XPOSE below
@@ -122,6 +125,11 @@ struct Params {
 };
 
 
+// the interleaved stereo PCM of frame `frame` of a DIRECT batch (frame_dwords = 2 * block_size)
+__device__ __forceinline__ const int32_t *inter_frame(const Params &p, uint32_t frame, uint32_t frame_dwords) {
+    return p.inter_tab ? p.inter_tab[frame] : p.inter + (size_t)frame * frame_dwords;
+}
+
 // largest block the generic kernels keep whole in LDS (k_fixed / k_fir: two arrays of it); larger
 // blocks (up to 65535, encode.rs:1418-1423) use per-workgroup arrays in HBM instead
 constexpr uint32_t LDS_BLOCK_LIMIT = 16384;
@@ -133,6 +141,8 @@ constexpr uint32_t FN = 4096;    // the block length of every preset but `fast`
 
 struct PackParams {
     uint64_t first_frame_number;
+    // a batch made of segments: the frame number of every frame, [n_frames]; nullptr: first_frame_number + f
+    const uint64_t *frame_numbers = nullptr;
     uint32_t sample_rate;
     uint32_t *out_words;      // packed bytes, viewed as big-endian-filled 32-bit words
     uint64_t *frame_off;      // [n_frames + 1] byte offsets
@@ -145,6 +155,10 @@ struct PackParams {
     // k_sub_finish; nullptr: the frame-per-workgroup k_frame64 assembles every wave-kernel frame
     struct SubEdgeRec { uint32_t w[8]; } *edges = nullptr;
 };
+__device__ __forceinline__ uint64_t frame_number_of(const PackParams &q, uint32_t frame) {
+    return q.frame_numbers ? q.frame_numbers[frame] : q.first_frame_number + frame;
+}
+
 
 // words reserved for a subframe's bit string: a chosen subframe is never longer than its
 // VERBATIM form (<= 40 + 33 n bits) plus the 16-byte frame header; multiple of 4 words

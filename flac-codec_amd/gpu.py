@@ -103,6 +103,40 @@ class GpuAnalyzer:
         if rc:
             raise GpuError(rc, "flacgpu_encode_device")
 
+    def encode_segments(self, segments, sample_rate):
+        """segments: [(host int32 array of whole blocks, first_frame_number), ...] of streams of this context's shape, encoded
+        as ONE batch (flacgpu_encode_segments).  Returns (bytes, offsets[total_frames + 1]): frames in segment order."""
+        arrs = [np.ascontiguousarray(a, dtype=np.int32) for a, _ in segments]
+        per = self.block_size * self.channels
+        segs = (_lib.Segment * len(arrs))()
+        total = 0
+        for i, (a, (_, first)) in enumerate(zip(arrs, segments)):
+            assert a.size % per == 0 and a.size
+            segs[i].pcm, segs[i].n_frames, segs[i].first_frame_number = a.ctypes.data, a.size // per, first
+            total += a.size // per
+        self.last_frames = total
+        off = (C.c_uint64 * (total + 1))()
+        tot = C.c_uint64(0)
+        cap = total * (per * 4 + 64) + 256
+        buf = np.empty(cap, dtype=np.uint8)
+        rc = _lib.lib().flacgpu_encode_segments(self._h, segs, len(arrs), sample_rate, C.c_void_p(buf.ctypes.data), cap, off,
+                                                C.byref(tot))
+        if rc:
+            raise GpuError(rc, "flacgpu_encode_segments")
+        return buf[: tot.value].tobytes(), [int(v) for v in off]
+
+    def encode_segments_device(self, segments, sample_rate, stream=None):
+        """segments: [(device pointer, n_frames, first_frame_number), ...]; asynchronous (fetch_frames() for the result)."""
+        segs = (_lib.Segment * len(segments))()
+        total = 0
+        for i, (ptr, n, first) in enumerate(segments):
+            segs[i].pcm, segs[i].n_frames, segs[i].first_frame_number = ptr, n, first
+            total += n
+        self.last_frames = total
+        rc = _lib.lib().flacgpu_encode_segments_device(self._h, segs, len(segments), sample_rate, C.c_void_p(stream or 0))
+        if rc:
+            raise GpuError(rc, "flacgpu_encode_segments_device")
+
     def pack_device(self, first_frame_number, sample_rate, stream=None):
         """Device-side frame assembly of the last analysed batch (bytes stay in HBM)."""
         rc = _lib.lib().flacgpu_pack_device(self._h, first_frame_number, sample_rate,

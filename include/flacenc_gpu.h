@@ -342,6 +342,31 @@ int flacgpu_pipeline_retire(flacgpu_pipeline *p, const uint8_t **frames, const u
 uint32_t flacgpu_pipeline_in_flight(const flacgpu_pipeline *p);
 uint32_t flacgpu_pipeline_depth(const flacgpu_pipeline *p);
 
+/* ---- a batch made of SEGMENTS: frames of SEVERAL streams in one analysis batch ------------------------------------------
+ * The reference encodes every file with an `Encoder` of its own, block by block (encode.rs:487-627 once per file); a batch of
+ * a few hundred frames leaves most of the GPU idle and still pays the kernels' launches and their serial walk over a block
+ * (256 frames of 24-bit stereo run at 0.3 of the per-sample rate of 8192).  Here runs of WHOLE blocks of several streams of
+ * the context's shape (bits per sample, channels, options) form one batch: segment s contributes n_frames frames numbered
+ * first_frame_number, first_frame_number + 1, ...; the frames come out concatenated in segment order (offsets: one entry per
+ * frame of the batch plus the end).  A stream's short last block is not a segment: it goes through flacgpu_encode_frames.
+ *   flacgpu_encode_segments_device  PCM resident in device memory, asynchronous like flacgpu_encode_device (results through
+ *                                   flacgpu_fetch_frames / flacgpu_device_buffer).  Interleaved stereo PCM of 4096-, 2304-,
+ *                                   2048-, 1152- or 1024-sample blocks (<= 24 bits) on 16-byte boundaries is read IN PLACE
+ *                                   through a per-frame address table (the buffers must stay valid until the results were
+ *                                   fetched); other shapes are gathered into the context's input buffer first.
+ *   flacgpu_encode_segments         host PCM (int32): every segment is uploaded to its place in the context's input buffer --
+ *                                   the gather costs nothing beyond the upload; synchronous, frames to `out`. */
+typedef struct {
+    const int32_t *pcm;            /* interleaved samples of n_frames whole blocks */
+    uint32_t n_frames;
+    uint32_t reserved;
+    uint64_t first_frame_number;   /* of the segment's first frame (the frame number counts the stream's blocks) */
+} flacgpu_segment;
+int flacgpu_encode_segments_device(flacgpu_ctx *ctx, const flacgpu_segment *segments, uint32_t n_segments,
+                                   uint32_t sample_rate, void *stream);
+int flacgpu_encode_segments(flacgpu_ctx *ctx, const flacgpu_segment *segments, uint32_t n_segments, uint32_t sample_rate,
+                            uint8_t *out, size_t cap, uint64_t *offsets, uint64_t *total);
+
 /* ---- several GPUs ------------------------------------------------------------------------------------
  * A FLAC frame depends on its own samples, the options and its frame number only (encode.rs:2284-2294), so a stream shards
  * by CONTIGUOUS FRAME RANGES with no data-path exchange.  What crosses shards is bookkeeping -- the reference's single

@@ -1,0 +1,103 @@
+"""Frames of SEVERAL streams in one analysis batch (flacgpu_encode_segments*; the reference runs one
+Encoder per file, /root/reference/src/encode.rs:487-627): every segment's frames must be the bytes the stream's own batch
+gives (and the oracle's), with the stream's own frame numbers, whatever the order and the sizes of the segments -- through
+the host path (segments uploaded to their places) and the device path (direct stereo input read in place through the
+per-frame address table; other shapes gathered)."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+from _compare import orc_options_for, planar_frames
+from _pcm import synth_fast, synth_hi
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(channels, bps, B, counts, seed):
+    out = []
+    for i, n in enumerate(counts):
+        gen = synth_hi if i % 2 else synth_fast
+        kw = dict(segment=B, orders=[2, 5, 9, 12]) if i % 2 else {}
+        out.append(np.ascontiguousarray(gen(seed + i, channels, bps, B * n, **kw)))
+    return out
+
+
+def _expect(stream, channels, bps, B, first, rate, max_lpc=12):
+    oopts = orc_options_for(B, 6, max_lpc, True, True)
+    out = []
+    for f, planar in enumerate(planar_frames(stream, channels, B)):
+        rc, fb, _ = orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)
+        assert rc == 0
+        out.append(fb)
+    return out
+
+
+@pytest.mark.parametrize("channels,bps,B", [(2, 24, 4096), (2, 16, 1152), (1, 16, 4096), (3, 24, 4096), (8, 24, 4096)])
+def test_host_segments_are_each_streams_own_frames(channels, bps, B):
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    counts = [5, 1, 9, 3, 7]
+    firsts = [0, 1000, 7, 0x7FFFFFF0, 31]
+    streams = _streams(channels, bps, B, counts, 8100 + channels)
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, channels, max_frames=sum(counts))
+    data, off = an.encode_segments(list(zip(streams, firsts)), 48000)
+    res, _ = an.verify_device(48000, 0)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (sum(counts), 0, 0, 0)
+    f = 0
+    for s, n, first in zip(streams, counts, firsts):
+        want = _expect(s, channels, bps, B, first, 48000)
+        for k in range(n):
+            assert data[off[f]:off[f + 1]] == want[k], f"segment starting at frame {first}: frame {k} differs from the oracle"
+            f += 1
+        # ... and what the stream's own batch gives
+        own, own_off = an.encode_frames(s, n, B, first, 48000)
+        assert own == b"".join(want) and own_off[n] == len(own)
+    an.close()
+
+
+@pytest.mark.parametrize("channels,bps", [(2, 24), (2, 16), (4, 24)])
+def test_device_segments_in_place_and_gathered(channels, bps):
+    """Direct stereo input is read in place through the address table (segments in shuffled order, one of them a view that
+    does not start on 16 bytes -> the whole batch is gathered instead); 4 channels always take the gather."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    B = 4096
+    counts = [6, 2, 11, 4]
+    firsts = [500, 0, 77, 123456]
+    streams = _streams(channels, bps, B, counts, 8200 + channels)
+    bufs = [torch.from_numpy(s).cuda() for s in streams]
+    odd = torch.empty(streams[1].size + 1, dtype=torch.int32, device="cuda")
+    odd[1:] = bufs[1]
+    torch.cuda.synchronize()
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, channels, max_frames=sum(counts))
+    want = [_expect(s, channels, bps, B, first, 44100) for s, first in zip(streams, firsts)]
+    for order, use_odd in (([2, 0, 3, 1], False), ([1, 3, 0, 2], True)):
+        segs = []
+        for i in order:
+            ptr = odd.data_ptr() + 4 if (use_odd and i == 1) else bufs[i].data_ptr()
+            segs.append((ptr, counts[i], firsts[i]))
+        an.encode_segments_device(segs, 44100)
+        data, off = an.fetch_frames()
+        f = 0
+        for i in order:
+            for k in range(counts[i]):
+                assert data[off[f]:off[f + 1]] == want[i][k], f"order {order}: stream {i} frame {k}"
+                f += 1
+        res, _ = an.verify_device(44100, 0)
+        assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (sum(counts), 0, 0, 0)
+    # the context goes back to ordinary batches afterwards (frame numbers from the call again)
+    own, own_off = an.encode_frames(streams[0], counts[0], B, 9, 44100)
+    assert own == b"".join(_expect(streams[0], channels, bps, B, 9, 44100))
+    an.close()
+
+
+def test_too_many_frames_and_empty_segments_are_refused():
+    from flac_codec_amd.gpu import GpuAnalyzer, GpuError
+
+    an = GpuAnalyzer(4096, 6, 12, True, True, 2, 0.5, 24, 2, max_frames=4)
+    s = synth_fast(8300, 2, 24, 4096 * 3)
+    with pytest.raises(GpuError):
+        an.encode_segments([(s, 0), (s, 100)], 48000)
+    an.close()
