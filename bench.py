@@ -321,6 +321,31 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                                    "once, submit and finish phases claimed by the worker threads, pooled lanes, the streams' MD5 chains on the shared 16-lane "
                                    "AVX-512 engines, waits that sleep, frames written by k_frame64 straight into pinned host memory); host PCM "
                                    "-> .flac bytes in caller buffers"}
+    # many SMALL streams: 256 streams of 32 blocks each (2.7 s of audio), one writer per stream against shared batches
+    # (flacenc_encode_many_coalesced); both compared with each other, one stream with the oracle
+    n_small, f_small = 256, 32
+    smalls = [pcm[i * 7 * BLOCK * C: (i * 7 + f_small) * BLOCK * C] for i in range(n_small)]
+    if all(x.size == f_small * BLOCK * C for x in smalls):
+        res = {}
+        for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
+            enc = BatchEncoder(opts(), threads=n_threads, **kw)
+            got = [bytes(v) for v in enc.encode(smalls, rate, bps, C, copy=False)]
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                enc.encode(smalls, rate, bps, C, copy=False)
+                ts.append(time.perf_counter() - t)
+            res[name] = (got, statistics.median(ts))
+        rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, smalls[5], total_known=True)
+        assert rc == 0 and res["coalesced"][0][5] == ref and res["coalesced"][0] == res["one_writer_per_stream"][0]
+        tot = n_small * f_small * BLOCK * C
+        out["many_small_streams"] = {
+            "streams": n_small, "frames_per_stream": f_small,
+            "one_writer_per_stream_Msamples/s": round(tot / res["one_writer_per_stream"][1] / 1e6, 1),
+            "coalesced_Msamples/s": round(tot / res["coalesced"][1] / 1e6, 1),
+            "byte_identical": True,
+            "note": "flacenc_encode_many against flacenc_encode_many_coalesced (runs of whole blocks of several streams in "
+                    "one flacgpu_encode_segments batch), median of 5 calls, host PCM -> .flac bytes, MD5 included"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
     batch = pcm[: 1024 * BLOCK * C]

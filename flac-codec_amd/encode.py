@@ -186,6 +186,7 @@ def _stream_lib():
         L.flacenc_encode_many.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32]
         L.flacenc_encode_many_devices.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32, C.POINTER(C.c_int),
                                                   C.c_uint32]
+        L.flacenc_encode_many_coalesced.argtypes = [po, C.POINTER(_CJob), C.c_size_t, C.c_uint32]
         _bound = True
     return L
 
@@ -564,10 +565,11 @@ class BatchEncoder:
     workers busy, each running FlacSampleWriter::new / write / finalize (encode.rs:487, 558, 624) for
     one stream at a time; output buffers are allocated once and reused by later calls."""
 
-    def __init__(self, options, threads=0, devices=None):
+    def __init__(self, options, threads=0, devices=None, coalesce=False):
         """devices: None (the options' device), "all" (every visible device) or a list of HIP ordinals -- stream i is
-        encoded whole on devices[i mod len] (flacenc_encode_many_devices)."""
-        self._opts, self._threads, self._devices = options, threads, devices
+        encoded whole on devices[i mod len] (flacenc_encode_many_devices).  coalesce: streams of one shape share analysis
+        batches (flacenc_encode_many_coalesced: many SMALL streams)."""
+        self._opts, self._threads, self._devices, self._coalesce = options, threads, devices, coalesce
         self._bufs = []
 
     def encode(self, streams, sample_rate, bits_per_sample, channels, copy=True):
@@ -592,7 +594,9 @@ class BatchEncoder:
             j.sample_rate, j.bits_per_sample, j.channels = sample_rate, bits_per_sample, channels
             j.out = self._bufs[i].ctypes.data
             j.out_cap = self._bufs[i].size
-        if self._devices is None:
+        if self._coalesce:
+            _check(L.flacenc_encode_many_coalesced(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+        elif self._devices is None:
             _check(L.flacenc_encode_many(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
         elif self._devices == "all":
             _check(L.flacenc_encode_many_devices(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads, None,

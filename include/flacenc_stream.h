@@ -185,6 +185,13 @@ int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n
  * one `Encoder` per file in the reference, encode.rs:1882-1980 -- the natural shard; nothing crosses devices).  devices ==
  * NULL with n_devices == FLACENC_ALL_DEVICES: every visible device; NULL / 0: opts->device as flacenc_encode_many.  An
  * ordinal may be listed more than once.  Output is byte-identical to flacenc_encode_many's. */
+/* The same for many SMALL streams: streams of one shape (sample rate, bits per sample, channels) share analysis batches --
+ * runs of whole blocks of several streams form one flacgpu_encode_segments call, so that a library of short files runs at
+ * the per-sample rate of large batches (a 256-frame batch of 24-bit stereo on its own: 0.3 of it).  A stream's short last
+ * block is encoded by a one-frame call, its MD5 runs on the shared engines, its metadata is rebuilt from the frame sizes
+ * (flacenc_stream_header).  Output byte-identical to flacenc_encode_many's, stream by stream; every stream is held in
+ * memory twice for the duration of the call (its samples and its MD5 byte string). */
+int flacenc_encode_many_coalesced(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads);
 #define FLACENC_ALL_DEVICES 0xFFFFFFFFu
 int flacenc_encode_many_devices(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads,
                                 const int *devices, uint32_t n_devices);

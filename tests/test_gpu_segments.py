@@ -101,3 +101,46 @@ def test_too_many_frames_and_empty_segments_are_refused():
     with pytest.raises(GpuError):
         an.encode_segments([(s, 0), (s, 100)], 48000)
     an.close()
+
+
+def test_many_small_streams_coalesced_give_each_streams_own_file():
+    """flacenc_encode_many_coalesced: streams of several shapes, lengths with and without a short last block, a stream
+    shorter than one block -- every .flac byte-identical to flacenc_encode_many's and the oracle's."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    o = Options.best()
+    cases = []
+    for i in range(20):
+        n = 4096 * (1 + i % 7) + (0 if i % 3 == 0 else 37 * i + 5)
+        cases.append(synth_fast(8400 + i, 2, 24, n))
+    cases.append(synth_fast(8450, 2, 24, 100))           # shorter than a block: the tail call alone
+    plain = BatchEncoder(o, threads=4).encode(cases, 48000, 24, 2)
+    co = BatchEncoder(o, threads=4, coalesce=True).encode(cases, 48000, 24, 2)
+    assert co == plain
+    oo = orc.options("best")
+    for i in (0, 1, 5, 20):
+        rc, ref, _ = orc.encode_stream(oo, 48000, 24, 2, cases[i], total_known=True)
+        assert rc == 0 and co[i] == ref, i
+    # another shape, other options (seek table by frames, padding, tags): the metadata is rebuilt from the frame sizes
+    o2 = Options.default().seektable_frames(3).padding(500).tag("TITLE", "x")
+    mono = [synth_fast(8500 + i, 1, 16, 4096 * (2 + i) + 11 * i) for i in range(6)]
+    assert BatchEncoder(o2, threads=3, coalesce=True).encode(mono, 44100, 16, 1) == BatchEncoder(o2, threads=3).encode(mono, 44100, 16, 1)
+
+
+def test_sixty_four_streams_of_512_frames():
+    """VERDICT r04 item 6's shape: 64 streams x 512 frames of 24-bit stereo; coalesced == one writer per stream, two of them
+    against the oracle."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    o = Options.best()
+    base = synth_fast(8600, 2, 24, 4096 * 512 + 4096 * 64)
+    streams = [base[2 * 4096 * i: 2 * 4096 * (i + 512)] for i in range(64)]     # overlapping windows: distinct, cheap to make
+    co = BatchEncoder(o, threads=8, coalesce=True).encode(streams, 48000, 24, 2, copy=False)
+    co = [bytes(v) for v in co]
+    plain = BatchEncoder(o, threads=8).encode(streams, 48000, 24, 2, copy=False)
+    for i in range(64):
+        assert co[i] == bytes(plain[i]), i
+    oo = orc.options("best")
+    for i in (0, 63):
+        rc, ref, _ = orc.encode_stream(oo, 48000, 24, 2, streams[i], total_known=True, threads=8)
+        assert rc == 0 and co[i] == ref
