@@ -321,9 +321,9 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                                    "once, submit and finish phases claimed by the worker threads, pooled lanes, the streams' MD5 chains on the shared 16-lane "
                                    "AVX-512 engines, waits that sleep, frames written by k_frame64 straight into pinned host memory); host PCM "
                                    "-> .flac bytes in caller buffers"}
-    # many SMALL streams: 256 streams of 32 blocks each (2.7 s of audio), one writer per stream against shared batches
+    # many SMALL streams: 1024 streams of 8 blocks each (0.7 s of audio), one writer per stream against shared batches
     # (flacenc_encode_many_coalesced); both compared with each other, one stream with the oracle
-    n_small, f_small = 256, 32
+    n_small, f_small = 1024, 8
     smalls = [pcm[i * 7 * BLOCK * C: (i * 7 + f_small) * BLOCK * C] for i in range(n_small)]
     if all(x.size == f_small * BLOCK * C for x in smalls):
         res = {}
@@ -345,7 +345,9 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
             "coalesced_Msamples/s": round(tot / res["coalesced"][1] / 1e6, 1),
             "byte_identical": True,
             "note": "flacenc_encode_many against flacenc_encode_many_coalesced (runs of whole blocks of several streams in "
-                    "one flacgpu_encode_segments batch), median of 5 calls, host PCM -> .flac bytes, MD5 included"}
+                    "one flacgpu_encode_segments batch), median of 5 calls, host PCM -> .flac bytes, MD5 included; the "
+                    "coalescing front end uploads from the callers' pageable buffers and wins below ~16 blocks per stream "
+                    "(tools/small_streams_probe.py: 256 x 32 blocks 1.1 against 2.3 Gsamples/s, 64 x 512: 2.5 against 7.4)"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
     batch = pcm[: 1024 * BLOCK * C]
@@ -1285,11 +1287,15 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(orc, cfg, w.pcm[0], F)
+        # (the headline workload's contexts and device buffers are released BEFORE the host-path legs: with them alive
+        # the pipelined leg measured 5-10 % below its stand-alone figure)
+        pcm0 = w.pcm[0]
+        n_ctx = len(w.ans)
+        w.close()
+        torch.cuda.empty_cache()
         e2e = None
         if world == 1 and not args.no_end_to_end:
-            e2e = end_to_end(cfg, w.pcm[0], local_rank, orc, args.e2e_batch_frames)
-        pcm0 = w.pcm[0]
-        w.close()
+            e2e = end_to_end(cfg, pcm0, local_rank, orc, args.e2e_batch_frames)
         others = None
         if world == 1 and not args.no_other_configs and not args.experiment and args.frames == FRAMES:
             others = {}
@@ -1328,7 +1334,7 @@ def main():
                                      f"own input buffer",
                        "baseline_config": args.config, "level": cfg["level"],
                        "frames_per_gpu": F, "frames_per_step": total_frames, "parallelism": f"frame ranges x{world}",
-                       "contexts": len(w.ans), "distinct_input_buffers": len(w.ans) if not strong else 1,
+                       "contexts": n_ctx, "distinct_input_buffers": n_ctx if not strong else 1,
                        "prewarm": f"{prewarm_steps} untimed steps ({args.prewarm_ms:.0f} ms) before the warm-up"},
             "sustained": sustained,
             "variants": variants,

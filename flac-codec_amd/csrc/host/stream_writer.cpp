@@ -1445,6 +1445,68 @@ int flacenc_encode_many_devices(const flacenc_options *opts_in, flacenc_job *job
 // through a one-frame call, its MD5 chain runs on the shared multi-stream engines over the whole byte string, and
 // everything in front of the first frame is rebuilt from the frame sizes (flacenc_stream_header) -- the same bytes
 // Encoder::new / encode / finalize_inner leave (encode.rs:1882-2110), stream by stream.
+namespace {
+// contexts of the coalescing front end, kept between calls (creating one sized for 8192 frames allocates ~1.5 GB of device
+// memory and costs ~100 ms: more than a whole call of 256 small streams), with their pinned output staging
+struct CoalesceSlot {
+    flacgpu_ctx *ctx = nullptr;
+    uint8_t *out = nullptr;      // pinned, flacgpu_packed_cap(ctx) bytes
+    size_t cap = 0;
+};
+struct CoalesceKey {
+    flacgpu_options g;
+    uint32_t bps, ch, frames;
+    int device;
+    bool operator==(const CoalesceKey &k) const {
+        return std::memcmp(&g, &k.g, sizeof g) == 0 && bps == k.bps && ch == k.ch && frames == k.frames && device == k.device;
+    }
+};
+struct CoalescePool {
+    std::mutex mu;
+    std::vector<std::pair<CoalesceKey, CoalesceSlot>> idle;
+    static CoalescePool &get() {
+        static CoalescePool *p = new CoalescePool();
+        return *p;
+    }
+    int take(const CoalesceKey &k, CoalesceSlot *s) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == k) {
+                    *s = idle[i].second;
+                    idle.erase(idle.begin() + i);
+                    return 0;
+                }
+        }
+        int rc = flacgpu_create(&k.g, k.bps, k.ch, k.device, k.frames, &s->ctx);
+        if (rc) return rc;
+        s->cap = flacgpu_packed_cap(s->ctx);
+        s->out = static_cast<uint8_t *>(flacgpu_host_alloc(s->cap));
+        if (!s->out) {
+            flacgpu_destroy(s->ctx);
+            s->ctx = nullptr;
+            return FLACGPU_ERR_HIP;
+        }
+        return 0;
+    }
+    void give(const CoalesceKey &k, const CoalesceSlot &s) {
+        CoalesceSlot drop;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            idle.emplace_back(k, s);
+            if (idle.size() > 8) {   // the oldest goes
+                drop = idle.front().second;
+                idle.erase(idle.begin());
+            }
+        }
+        if (drop.ctx) {
+            flacgpu_destroy(drop.ctx);
+            flacgpu_host_free(drop.out);
+        }
+    }
+};
+}  // namespace
+
 int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
     if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
     if (int e = options_error(*opts_in)) return e;
@@ -1555,13 +1617,23 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 jobs[s.job].pack_ms += now_ms() - t0;
             }
             flacgpu_ctx *ctx = nullptr;
-            std::vector<uint8_t> out;
+            CoalesceSlot slot;
+            const CoalesceKey key{g, sh.bps, sh.ch, batch_cap, device};
+            struct View {   // the slot's pinned staging, addressed like the vector it replaces
+                uint8_t *p = nullptr;
+                size_t n = 0;
+                uint8_t *data() const { return p; }
+                size_t size() const { return n; }
+                uint8_t *begin() const { return p; }
+            } out;
             std::vector<uint64_t> off;
             auto need_ctx = [&]() -> int {
                 if (ctx) return 0;
-                const int rc = flacgpu_create(&g, sh.bps, sh.ch, device, batch_cap, &ctx);
+                const int rc = CoalescePool::get().take(key, &slot);
                 if (rc) return rc;
-                out.resize(flacgpu_packed_cap(ctx));
+                ctx = slot.ctx;
+                out.p = slot.out;
+                out.n = slot.cap;
                 off.resize((size_t)batch_cap + 1);
                 return 0;
             };
@@ -1608,7 +1680,7 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                     s.chunks.emplace_back(s.whole, std::vector<uint8_t>(out.begin(), out.begin() + total));
                 }
             }
-            if (ctx) flacgpu_destroy(ctx);
+            if (ctx) CoalescePool::get().give(key, slot);
         };
         const unsigned workers = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, std::max(batches.size() + tails.size(), ids.size())));
         WorkerPool::get().run(workers - 1, work);
