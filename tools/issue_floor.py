@@ -27,7 +27,7 @@ ALIAS = {
     "v_and_b32": "v_and_b32", "v_or_b32": "v_or_b32", "v_not_b32": "v_not_b32", "v_lshrrev_b32": "v_lshrrev_b32",
     "v_ashrrev_i32": "v_ashrrev_i32", "v_lshlrev_b32": "v_lshlrev_b32", "v_mov_b32": "v_mov_b32",
     "v_sad_u32": "v_sad_u32", "v_add3_u32": "v_add3_u32", "v_or3_b32": "v_or3_b32", "v_bitop3_b32": "v_bitop3_b32",
-    "v_mad_i64_i32": "mad_i64_chain", "v_mad_u64_u32": "mad_i64_chain", "v_mad_i32_i24": "v_mad_i32_i24",
+    "v_mad_i64_i32": "v_mad_i64_i32", "v_mad_u64_u32": "mad_i64_chain", "v_mad_i32_i24": "v_mad_i32_i24",
     "v_mad_u32_u24": "v_mad_i32_i24", "v_lshl_add_u64": "v_lshl_add_u64", "v_ashrrev_i64": "v_ashrrev_i64",
     "v_lshrrev_b64": "v_ashrrev_i64", "v_lshlrev_b64": "v_ashrrev_i64", "v_alignbit_b32": "v_alignbit_b32",
     "v_cndmask_b32": "v_cndmask_b32", "v_readlane_b32": "v_readlane_b32", "v_readfirstlane_b32": "v_readfirstlane_b32",
@@ -120,9 +120,9 @@ def pick_cand(blocks, taps, fixed_subs):
         n = Counter(t.split()[0] for t in ins)
         mads = n["v_mad_i64_i32"]
         big = len(ins) >= 150
-        if mads >= 64:                                       # a FIR instantiation (or the overflow test)
-            if mads == 64 * taps and n["v_bitop3_b32"] == 0:
-                chosen.append((name, ins, inner))
+        if mads >= 64 and n["v_bitop3_b32"]:
+            continue                                         # the overflow test of the checked re-run: not taken
+        if mads:                                             # r05: a turn of fir64_dyn (the FIR is added below)
             continue
         if big and n["v_sad_u32"] >= 64:                    # order statistics
             chosen.append((name, ins, inner))
@@ -143,6 +143,11 @@ def pick_cand(blocks, taps, fixed_subs):
             continue                                         # 31-bit fallback / k = 0 variants: not taken
         if not big:
             chosen.append((name, ins, inner))
+    # r05 (fir64_dyn): the FIR is one region whose turns add tap pairs under scalar tests -- a wave with `taps` taps runs
+    # taps mads, one 64-bit shift and one subtraction per sample
+    if taps < 99:
+        chosen.append(("fir64_dyn", ["v_mad_i64_i32 v[0:1], vcc, v0, s0, v[0:1]"] * (64 * taps) +
+                       ["v_ashrrev_i64 v[0:1], s0, v[0:1]"] * 64 + ["v_sub_u32 v0, v0, v0"] * 64, False))
     return chosen
 
 
@@ -180,8 +185,8 @@ def floor(kernel, blocks, cost, dyn_insts, units=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm-dir", default=os.path.join(ROOT, "flac-codec_amd", "csrc"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_issue_floor.json"))
-    ap.add_argument("--tag", default="r04", help="round tag of the counter collections (profiles/<tag>_c_valu.json, <tag>_cfg2_valu.json ...)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_issue_floor.json"))
+    ap.add_argument("--tag", default="r05", help="round tag of the counter collections (profiles/<tag>_c_valu.json, <tag>_cfg2_valu.json ...)")
     ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r03_issue_rate_ubench.json"))
     a = ap.parse_args()
     cost = costs(a.ubench)
