@@ -20,6 +20,6 @@ for f in glob.glob(out+"/g*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:58]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
-    if any(x in k for x in ("k_cand64","k_autocorr4","k_frame64","k_deinterleave2","k_sub64")):
+    if any(x in k for x in ("k_cand64","k_autocorr4","k_frame64","k_deinterleave2","k_sub64")) and "mfma" not in k:
         print(k, {c:round(sum(x)/len(x)) for c,x in v.items()})
 PY
