@@ -270,9 +270,12 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     # host PCM -> frames in host memory with both link directions in flight (flacgpu_pipeline_*), two batch sizes; measured
     # FIRST: the writers below leave a pool of 64 lanes (128 HIP streams) and parked threads behind, beside which this loop
     # ran 5-10 % slower
-    out["pipelined_pcie"] = pipelined_pcie(torch, cfg, pcm, device, orc, 2048, depth=4, batches=16)
+    # (64 batches per timed loop: with 16 the loop's ramp -- the first uploads with nothing to overlap -- and its drain were
+    # 6-10 % of it, the "loss inside the bench" of VERDICT r04 item 9: bench.pipelined_pcie from a bare script gives 11.35 /
+    # 13.5 Gsamples/s with 16 batches and 12.67 / 14.9 with 64, tools/pp_bench_fn.py)
+    out["pipelined_pcie"] = pipelined_pcie(torch, cfg, pcm, device, orc, 2048, depth=4, batches=64)
     out["pipelined_pcie"]["batch_8192"] = {k: v for k, v in pipelined_pcie(torch, cfg, pcm, device, orc, FRAMES, depth=3,
-                                                                            batches=6).items() if k not in ("link", "note")}
+                                                                            batches=16).items() if k not in ("link", "note")}
     out["host"] = host_capacity((bps + 7) // 8)   # (after the pipelined leg: its 16 hashing threads use up the CPU quota of the period)
     # one stream: 2048 blocks (~3 minutes of 48 kHz audio)
     one = pcm[: 2048 * BLOCK * C]

@@ -137,8 +137,26 @@ int flacgpu_multi_device_of(const flacgpu_multi *m, uint32_t shard) {
 }
 
 // One shard's range [lo, hi) of the call, through its pipeline in sub-batches of <= max_frames frames.
+static void run_shard_body(flacgpu_multi *m, Shard &s, const uint8_t *pcm, uint32_t bytes_per_sample, uint64_t lo, uint64_t hi,
+                           uint64_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate);
+// (a shard thread must not let an exception -- std::bad_alloc of its staging vectors -- cross the C boundary)
 static void run_shard(flacgpu_multi *m, Shard &s, const uint8_t *pcm, uint32_t bytes_per_sample, uint64_t lo, uint64_t hi,
                       uint64_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate) {
+    try {
+        run_shard_body(m, s, pcm, bytes_per_sample, lo, hi, n_frames, last_frame_len, first_frame_number, sample_rate);
+    } catch (...) {
+        while (s.pipe && flacgpu_pipeline_in_flight(s.pipe)) {
+            const uint8_t *fr;
+            const uint64_t *off;
+            uint32_t nf;
+            uint64_t total;
+            if (flacgpu_pipeline_retire(s.pipe, &fr, &off, &nf, &total) != FLACGPU_OK) break;
+        }
+        s.rc = FLACGPU_ERR_HIP;
+    }
+}
+static void run_shard_body(flacgpu_multi *m, Shard &s, const uint8_t *pcm, uint32_t bytes_per_sample, uint64_t lo, uint64_t hi,
+                           uint64_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate) {
     s.rc = FLACGPU_OK;
     s.bytes.clear();
     s.off.assign(1, 0);

@@ -403,6 +403,8 @@ int flacgpu_device_count(void);   /* visible HIP devices */
  *                                context in rotation, asynchronous; flacgpu_multi_wait drains every context of every shard;
  *                                flacgpu_multi_counters reads the records of every shard's LAST batch (and merges them);
  *                                flacgpu_multi_last_context hands that batch's context out (fetch / verify). */
+/* A flacgpu_multi belongs to one calling thread at a time (like a flacgpu_ctx); flacgpu_multi_encode runs its shards on
+ * threads of its own for the duration of the call. */
 typedef struct flacgpu_multi flacgpu_multi;
 int flacgpu_multi_create(const flacgpu_options *opts, uint32_t bits_per_sample, uint32_t channels, const int *devices,
                          uint32_t n_devices, uint32_t max_frames, uint32_t depth, flacgpu_multi **out);
