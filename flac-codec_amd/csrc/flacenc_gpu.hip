@@ -683,6 +683,16 @@ static bool direct_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last
            (size_t)frame_fb_words(p.channels, c->bps, B) * sizeof(int32_t) <= 150 * 1024;
 }
 
+// interleaved INDEPENDENT channels whose batch k_autocorr4's producers read themselves (Params::split_src; analyze_impl adds
+// the conditions on the call: layout, alignment, no stream-width upload)
+static bool split_input_ok(const flacgpu_ctx *c, const Params &p, uint32_t last_len) {
+    const uint32_t B = p.block_size;
+    return !c->stereo4 && c->channels >= 1 && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 && B == FN &&
+           last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
+           !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 || c->knobs.ac_private ||
+             c->knobs.experiment_mfma_ac);
+}
+
 // k_layout's tiles find each other through PackParams::tile_sync, whose words carry the launch's 24-bit epoch: a new
 // one per launch, the words wiped (in stream order) when the counter wraps
 static int next_layout_epoch(flacgpu_ctx *c, PackParams &q, hipStream_t st) {
@@ -811,11 +821,8 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     // frame on the wave kernels (no generic-path frame reads the rows before the autocorrelation has written them).
     // (one channel: the input is its own planar row -- nothing to split, but the ORs still come out of the
     // autocorrelation instead of a k_orbits pass over the batch)
-    const bool split = !direct && !packed_bytes && aligned16 && (layout == FLACGPU_LAYOUT_INTERLEAVED || c->channels == 1) && !c->stereo4 &&
-                       c->channels >= 1 && (c->channels >= 2 || planar_direct) && c->ncand == c->channels && p.max_lpc_order >= 1 && p.max_lpc_order <= 16 &&
-                       B == FN && last_len == B && p.ac_split != 2 && (c->bps <= 25u) && p.max_po <= 6 &&
-                       !(c->knobs.no_direct || c->knobs.no_fast || c->knobs.no_w64 || c->knobs.no_ac3 ||
-                         c->knobs.ac_private || c->knobs.experiment_mfma_ac);
+    const bool split = !direct && !packed_bytes && aligned16 && (layout == FLACGPU_LAYOUT_INTERLEAVED || c->channels == 1) &&
+                       (c->channels >= 2 || planar_direct) && split_input_ok(c, p, last_len);
     // 3, 4, 6 or 8 channels: the candidate and subframe kernels read the interleaved batch in place as well (load_lane_xpose: a
     // workgroup fetches a whole frame -- or half of a 6- or 8-channel one -- together) -- the planar rows, half of the
     // autocorrelation kernel's HBM traffic, are not written at all; like a DIRECT stereo batch, the caller's buffer is then
@@ -831,6 +838,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
                        (C_ == 3 || C_ == 4 || ((C_ == 8 || C_ == 6) && c->d_edges));
     if (split) {
         p.split_src = d_pcm;
+        if (c->seg_active && c->seg_direct) p.inter_tab = c->d_seg_ptr;   // (segments: every frame's address from the table)
         p.split_dst = (c->channels == 1 || xpose) ? nullptr : c->d_planar;
         p.xpose = xpose ? 1u : 0u;
         if (c->channels == 1) p.planar = d_pcm;   // [frame][B] with ldb == B (planar_direct)
@@ -838,6 +846,10 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
             c->planar_valid = false;
             c->direct_src = d_pcm;
         }
+    }
+    if (c->seg_active && c->seg_direct && !direct && !split) {
+        g_last_error = "internal: a batch of segments was announced as read in place, but the analysis takes a copying path";
+        return FLACGPU_ERR_UNSUPPORTED;
     }
     if (!direct && !split) begin(0);
     bool have_orbits = direct || split;
@@ -1403,7 +1415,8 @@ static int segments_common(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t
     const size_t frame_ints = (size_t)B * c->channels;
     Params probe;
     fill_params(c, (uint32_t)total, B, probe);
-    bool direct = on_device && direct_input_ok(c, probe, B);
+    // read in place (stereo: Params::inter; 2..8 independent channels: Params::split_src) or gathered into d_in
+    bool direct = on_device && (direct_input_ok(c, probe, B) || (c->channels >= 2 && split_input_ok(c, probe, B)));
     for (uint32_t i = 0; i < n_segs && direct; i++) direct = ((uintptr_t)segs[i].pcm & 15u) == 0;
     uint64_t *fn = c->h_seg;
     const int32_t **ptr = reinterpret_cast<const int32_t **>(c->h_seg + F);

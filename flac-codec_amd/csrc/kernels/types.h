@@ -129,6 +129,10 @@ struct Params {
 __device__ __forceinline__ const int32_t *inter_frame(const Params &p, uint32_t frame, uint32_t frame_dwords) {
     return p.inter_tab ? p.inter_tab[frame] : p.inter + (size_t)frame * frame_dwords;
 }
+// ... of frame `frame` of a SPLIT / XPOSE batch of interleaved independent channels (frame_dwords = block_size * channels)
+__device__ __forceinline__ const int32_t *split_frame(const Params &p, uint32_t frame, uint32_t frame_dwords) {
+    return p.inter_tab ? p.inter_tab[frame] : p.split_src + (size_t)frame * frame_dwords;
+}
 
 // largest block the generic kernels keep whole in LDS (k_fixed / k_fir: two arrays of it); larger
 // blocks (up to 65535, encode.rs:1418-1423) use per-workgroup arrays in HBM instead

@@ -350,10 +350,13 @@ uint32_t flacgpu_pipeline_depth(const flacgpu_pipeline *p);
  * first_frame_number, first_frame_number + 1, ...; the frames come out concatenated in segment order (offsets: one entry per
  * frame of the batch plus the end).  A stream's short last block is not a segment: it goes through flacgpu_encode_frames.
  *   flacgpu_encode_segments_device  PCM resident in device memory, asynchronous like flacgpu_encode_device (results through
- *                                   flacgpu_fetch_frames / flacgpu_device_buffer).  Interleaved stereo PCM of 4096-, 2304-,
- *                                   2048-, 1152- or 1024-sample blocks (<= 24 bits) on 16-byte boundaries is read IN PLACE
- *                                   through a per-frame address table (the buffers must stay valid until the results were
- *                                   fetched); other shapes are gathered into the context's input buffer first.
+ *                                   flacgpu_fetch_frames / flacgpu_device_buffer).  Every shape flacgpu_analyze_device reads in
+ *                                   place -- interleaved stereo of 4096-, 2304-, 2048-, 1152- or 1024-sample blocks (<= 24
+ *                                   bits), 2..8 interleaved independent channels of 4096-sample blocks (LPC order 1..16) --
+ *                                   is read IN PLACE through a per-frame address table when every segment starts on a
+ *                                   16-byte boundary (the buffers must stay valid until the results were fetched); other
+ *                                   shapes (one channel, other block sizes, 32-bit samples) are gathered into the
+ *                                   context's input buffer first.
  *   flacgpu_encode_segments         host PCM (int32): every segment is uploaded to its place in the context's input buffer --
  *                                   the gather costs nothing beyond the upload; synchronous, frames to `out`. */
 typedef struct {

@@ -55,10 +55,11 @@ def test_host_segments_are_each_streams_own_frames(channels, bps, B):
     an.close()
 
 
-@pytest.mark.parametrize("channels,bps", [(2, 24), (2, 16), (4, 24)])
+@pytest.mark.parametrize("channels,bps", [(2, 24), (2, 16), (4, 24), (8, 24), (3, 16), (6, 24), (5, 24), (1, 16)])
 def test_device_segments_in_place_and_gathered(channels, bps):
-    """Direct stereo input is read in place through the address table (segments in shuffled order, one of them a view that
-    does not start on 16 bytes -> the whole batch is gathered instead); 4 channels always take the gather."""
+    """Direct stereo input and interleaved independent channels (transposing loads for 3 / 4 / 6 / 8, split producers for 5)
+    are read in place through the address table (segments in shuffled order); with one of them a view that does not start
+    on 16 bytes the whole batch is gathered instead, as one-channel streams always are."""
     import torch
 
     from flac_codec_amd.gpu import GpuAnalyzer
