@@ -65,6 +65,8 @@ extern "C" void flacgpu_early_download_counters(uint64_t *queued, uint64_t *with
 // profiles/r05_defer_fixed.json: 0.6 % of the deferred candidates of the high-order input take the re-read, none of SURVEY's
 // input defers at all; at 2 bits every candidate of SURVEY's input deferred and re-read: +11 % on the kernel)
 static constexpr uint32_t kDeferMargin16 = 48;
+static constexpr uint32_t kDeferWords = DEFER_SLOTS * DEFER_SLOT_WORDS;   // Params::defer_stats
+static constexpr uint32_t kTurnWords = 4;   // Params::turn_counter words in front of the counters (16-byte aligned counters behind them)
 Knobs read_knobs() {
     Knobs k;
     auto on = [](const char *name) { return getenv(name) != nullptr; };
@@ -118,6 +120,7 @@ namespace {
 using namespace flacgpu_k;
 
 struct flacgpu_ctx;
+static uint32_t *defer_stats_of(const flacgpu_ctx *c);
 static int ctx_sync(flacgpu_ctx *c);
 static hipStream_t ctx_stream(flacgpu_ctx *c);
 
@@ -133,6 +136,7 @@ struct flacgpu_ctx {
     LpcParams *d_lpc = nullptr;
     FrameInfo *d_finfo = nullptr;
     flacgpu_frame_plan *d_fplan = nullptr;
+    uint32_t *d_stats_base = nullptr;   // Params::turn_counter words in front of d_stats (zeroed by the same memset)
     uint32_t *d_stats = nullptr;
     uint32_t *d_orbits = nullptr;   // OR of all samples per (frame, candidate); = d_stats + 4
     uint32_t *d_ties = nullptr;     // candidates whose LPC order estimates tie (k_lpc), [F * NC]
@@ -512,9 +516,12 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_lpc, F * NC);
     ALLOC(c->d_finfo, F);
     ALLOC(c->d_fplan, F);
-    ALLOC(c->d_stats, 4 + F * NC + 2);  // counters, then the per-candidate ORs (one memset per batch), then Params::defer_stats
+    // Params::turn_counter (4 words), counters, then the per-candidate ORs (one memset per batch over all three), then Params::defer_stats
+    ALLOC(c->d_stats_base, kTurnWords + 4 + F * NC + kDeferWords + 16);
+    c->d_stats = c->d_stats_base + kTurnWords;
+    HIP_TRY(hipMemset(c->d_stats_base, 0, kTurnWords * sizeof(uint32_t)));
     c->d_orbits = c->d_stats + 4;
-    HIP_TRY(hipMemset(c->d_stats + 4 + F * NC, 0, 2 * sizeof(uint32_t)));   // Params::defer_stats, cumulative
+    HIP_TRY(hipMemset(defer_stats_of(c), 0, kDeferWords * sizeof(uint32_t)));   // Params::defer_stats, cumulative
     // worst case: every subframe VERBATIM at 32 bits + headers
     c->packed_cap = (uint64_t)F * C * B * 4 + (uint64_t)F * (C * 8 + 64) + 256;
     ALLOC(c->d_packed, c->packed_cap / 4 + 8);
@@ -569,7 +576,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_in); (void)hipFree(c->d_planar); (void)hipFree(c->d_resid); (void)hipFree(c->d_window_full);
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
-    (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats_base);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_tile_sync);
     if (c->d_seg_fn) (void)hipFree(c->d_seg_fn);
     if (c->d_seg_ptr) (void)hipFree(c->d_seg_ptr);
@@ -591,6 +598,11 @@ int flacgpu_set_timing(flacgpu_ctx *c, int enable) {
     return 0;
 }
 
+// Params::defer_stats: behind the ORs, on a 64-byte line of its own
+static uint32_t *defer_stats_of(const flacgpu_ctx *c) {
+    const size_t off = (kTurnWords + 4 + (size_t)c->max_frames * c->ncand + 15u) & ~(size_t)15u;
+    return c->d_stats_base + off;
+}
 static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_len, Params &p) {
     const uint32_t B = c->opts.block_size;
     memset(&p, 0, sizeof p);
@@ -648,7 +660,8 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.fir_suspect_bits = c->knobs.fir_suspect_bits ? c->knobs.fir_suspect_bits : 30u;
     p.defer_fixed = c->knobs.defer_fixed >= 0 ? (uint32_t)c->knobs.defer_fixed : 1u;
     p.defer_margin16 = c->knobs.defer_margin16 >= 0 ? (uint32_t)c->knobs.defer_margin16 : kDeferMargin16;
-    p.defer_stats = c->d_stats + 4 + (size_t)c->max_frames * c->ncand;   // behind the ORs; cumulative, zeroed at creation
+    p.defer_stats = defer_stats_of(c);   // behind the ORs; cumulative, zeroed at creation
+    p.turn_counter = c->d_stats_base;
 }
 
 // stream == NULL: the context's own (non-blocking) stream, ordered AFTER whatever the caller has
@@ -797,7 +810,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     const bool ranged = c->rng_cnt != 0;                 // (flacgpu_encode_device checked that this batch can be cut)
     const uint32_t rf0 = ranged ? c->rng_f0 : 0u, rcnt = ranged ? c->rng_cnt : n_frames;
     const bool first_range = rf0 == 0;
-    if (first_range) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)ncb), st));  // + d_orbits
+    if (first_range) HIP_TRY(hipMemsetAsync(c->d_stats_base, 0, sizeof(uint32_t) * (kTurnWords + 4 + (size_t)ncb), st));  // + d_orbits
     // DIRECT input: interleaved i32 stereo PCM of whole 4096-sample blocks is read in place by the
     // autocorrelation, candidate and frame kernels (no K0 split; the ORs come out of k_autocorr4, so
     // k_candinfo runs after it) -- see kernels/autocorr.inc.  The caller's buffer is then the only copy of
@@ -1336,7 +1349,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
     // (planar rows are read in place unless the caller asked for a copy: FLACGPU_TUNE_COPY_INPUT / FLACGPU_NO_DIRECT)
     const bool planar_direct = (layout == FLACGPU_LAYOUT_PLANAR) && (B % 4 == 0) && !c->knobs.no_direct && ((uintptr_t)d_pcm & 15u) == 0;
     if (planar_direct) p.planar = d_pcm;
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st0));  // + d_orbits
+    HIP_TRY(hipMemsetAsync(c->d_stats_base, 0, sizeof(uint32_t) * (kTurnWords + 4 + (size_t)n_frames * c->ncand), st0));  // + d_orbits
     HIP_TRY(hipEventRecord(c->ev_fork, st0));
     HIP_TRY(hipStreamWaitEvent(st1, c->ev_fork, 0));
     const uint32_t h = ((n_frames / 2) + 15u) & ~15u;  // 16 frames = one autocorrelation wave group
@@ -1348,6 +1361,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         Params r = p;
         r.f0 = half ? h : 0;
         r.fcount = half ? n_frames - h : h;
+        r.turn_counter = c->d_stats_base + half;   // the two ranges' candidate kernels may run side by side
         const uint32_t ncb = r.fcount * c->ncand;
         bool have_orbits = false;
         if (!planar_direct) have_orbits = launch_k0(c, d_pcm, layout, n_frames, last_len, r.f0, r.fcount, st);
@@ -1525,7 +1539,7 @@ int flacgpu_pack_plans(flacgpu_ctx *c, const int32_t *pcm, uint32_t n_frames, ui
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
     HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(uint32_t) * (4 + (size_t)n_frames * c->ncand), st));
+    HIP_TRY(hipMemsetAsync(c->d_stats_base, 0, sizeof(uint32_t) * (kTurnWords + 4 + (size_t)n_frames * c->ncand), st));
     (void)launch_k0(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, 0, n_frames, st);
     HIP_TRY(hipMemcpyAsync(c->d_fplan, plans, sizeof(*plans) * n_frames, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_out, subs, sizeof(*subs) * n_frames * C, hipMemcpyHostToDevice, st));
@@ -2194,10 +2208,13 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     out->order_ties_resolved = c->ties_resolved;
     out->fir_recheck = s[3];
     out->fir_rechecked = c->fir_rechecked;
-    uint32_t d[2];
-    if (int rc = copy_sync(c, d, c->d_stats + 4 + (size_t)c->max_frames * c->ncand, sizeof d, hipMemcpyDeviceToHost)) return rc;
-    out->fixed_decided = d[0];
-    out->fixed_refetched = d[1];
+    uint32_t d[kDeferWords];
+    if (int rc = copy_sync(c, d, defer_stats_of(c), sizeof d, hipMemcpyDeviceToHost)) return rc;
+    out->fixed_decided = out->fixed_refetched = 0;
+    for (uint32_t i = 0; i < DEFER_SLOTS; i++) {
+        out->fixed_decided += d[DEFER_SLOT_WORDS * i];
+        out->fixed_refetched += d[DEFER_SLOT_WORDS * i + 1];
+    }
     return FLACGPU_OK;
 }
 

@@ -121,7 +121,11 @@ struct Params {
     // samples and counts after all.  0: never (A/B), 1: by the estimate, 2: whenever LPC parameters exist (TEST: every
     // undecided candidate takes the re-fetch).  defer_stats: {waves that deferred, of those: re-fetched}, cumulative.
     uint32_t defer_fixed, defer_margin16;
-    uint32_t *defer_stats;
+    uint32_t *defer_stats;   // [DEFER_SLOTS][DEFER_SLOT_WORDS]: the pair {deferred, re-fetched} per slot
+    // k_cand64p's DYNAMIC TURNS (r05): the launch's ticket counter -- 0 when a launch begins (zeroed with the batch's
+    // counters by the host, and again by whoever draws a launch's last ticket); launches of one context that may run
+    // concurrently (the two ranges of FLACGPU_TUNE_TWO_RANGES) use different words
+    uint32_t *turn_counter;
 };
 
 
@@ -140,6 +144,7 @@ constexpr uint32_t LDS_BLOCK_LIMIT = 16384;
 __host__ __device__ constexpr uint32_t big_scratch_ints(uint32_t block_size) {
     return 2u * (block_size + block_size / 16u + 16u) + 64u;   // x[n] | r[n] with the RIDX padding
 }
+constexpr uint32_t DEFER_SLOTS = 64, DEFER_SLOT_WORDS = 16;   // Params::defer_stats: workgroup w adds to slot w % 64 (a 64-byte line each)
 constexpr int AC_LD = 36;        // row stride of the ac buffer (max lag group count rounded up)
 constexpr uint32_t FN = 4096;    // the block length of every preset but `fast`
 
