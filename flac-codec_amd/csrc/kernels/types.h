@@ -163,6 +163,9 @@ struct PackParams {
     // k_sub64 (one workgroup per subframe, kernels/sub64.inc): the subframes' edge records [frame][channel], merged by
     // k_sub_finish; nullptr: the frame-per-workgroup k_frame64 assembles every wave-kernel frame
     struct SubEdgeRec { uint32_t w[8]; } *edges = nullptr;
+    // k_frame64: words of the workgroup's LDS image as launched (a multiple of 4; set by launch_frame64_nt) -- the image is
+    // zeroed whole, without waiting for the frame's length to arrive from memory; 0: zero the frame's own words only
+    uint32_t fb_words = 0;
 };
 __device__ __forceinline__ uint64_t frame_number_of(const PackParams &q, uint32_t frame) {
     return q.frame_numbers ? q.frame_numbers[frame] : q.first_frame_number + frame;

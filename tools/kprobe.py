@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--frames", type=int, default=bench.FRAMES)
+    ap.add_argument("--chunk-msamples", type=int, default=-1, help="FLACGPU_TUNE_CHUNK_MSAMPLES of every context (-1: default)")
+    ap.add_argument("--own-buffers", action="store_true", help="every context reads its own copy of the batch (as bench.py does)")
     a = ap.parse_args()
     import torch
     from flac_codec_amd.gpu import GpuAnalyzer, LAYOUT_INTERLEAVED, LAYOUT_PLANAR
@@ -37,12 +39,16 @@ def main():
     lay = LAYOUT_PLANAR if a.layout == "planar" else LAYOUT_INTERLEAVED
     ans = [GpuAnalyzer(B, cfg["po"], cfg["lpc"], True, True, 2, 0.5, BPS, C, max_frames=F) for _ in range(a.contexts)]
     streams = [torch.cuda.Stream() for _ in ans]
+    if a.chunk_msamples >= 0:
+        for an in ans:
+            an.set_tuning(an.TUNE_CHUNK_MSAMPLES, a.chunk_msamples)
+    bufs = [d] + [d.clone() for _ in range(len(ans) - 1)] if a.own_buffers else [d] * len(ans)
     n = [0]
 
     def step():
         i = n[0] % len(ans)
         n[0] += 1
-        ans[i].encode_device(d.data_ptr(), F, B, 0, RATE, stream=streams[i].cuda_stream, layout=lay)
+        ans[i].encode_device(bufs[i].data_ptr(), F, B, 0, RATE, stream=streams[i].cuda_stream, layout=lay)
 
     t = time.perf_counter()
     while time.perf_counter() - t < 0.3:
@@ -58,7 +64,7 @@ def main():
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t) / a.steps * 1e3)
     data, off = ans[0].fetch_frames(F)
-    print(f"layout={a.layout} contexts={a.contexts} config={a.config}: ms/step {min(res):.4f} (runs {[round(r, 4) for r in res]}), "
+    print(f"layout={a.layout} contexts={a.contexts} config={a.config} chunk={a.chunk_msamples} own={a.own_buffers}: ms/step {min(res):.4f} (runs {[round(r, 4) for r in res]}), "
           f"bytes {off[F]}")
 
 
