@@ -380,3 +380,32 @@ def test_batches_that_do_not_start_on_16_bytes_take_the_copying_path():
             torch.cuda.synchronize()
             assert an.fetch_frames(n) == want, (ch, shift)
         an.close()
+
+
+@pytest.mark.parametrize("grid", ["1", "3", "64", "5000"])
+def test_dynamic_turns_any_grid_and_batch_after_batch(monkeypatch, grid):
+    """k_cand64p draws its frames from a per-launch counter (Params::turn_counter): whatever the number of resident
+    workgroups -- fewer than frames, more than frames, one -- and batch after batch of different sizes on ONE context (the
+    launch's last draw resets the counter), every frame is analysed exactly once: the oracle's bytes, and nothing drawn twice."""
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    monkeypatch.setenv("FLACGPU_CAND_GRID", grid)
+    first, rate, bps = 11, 48000, 24
+    pcm = synth_fast(990, 2, bps, B * 37)
+    oopts = orc_options_for(B, 6, 12, True, True)
+    want = [orc.encode_frame(oopts, rate, bps, planar, frame_number=first + f)[1] for f, planar in enumerate(planar_frames(pcm, 2, B))]
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, 2, max_frames=37)
+    for n, f0 in ((37, 0), (5, 3), (1, 36), (20, 17), (37, 0)):   # several launches, sizes on both sides of the grid
+        data, off = an.encode_frames(pcm[f0 * 2 * B:(f0 + n) * 2 * B], n, B, first + f0, rate)
+        for f in range(n):
+            assert data[off[f]:off[f + 1]] == want[f0 + f], (grid, n, f0, f)
+    an.close()
+    # without LPC (the SELF instantiation: its next image is requested EARLY, the ticket is published at the first barrier)
+    oopts0 = orc_options_for(B, 6, 0, True, True)
+    an = GpuAnalyzer(B, 6, 0, True, True, 2, 0.5, bps, 2, max_frames=37)
+    for n, f0 in ((37, 0), (2, 9)):
+        data, off = an.encode_frames(pcm[f0 * 2 * B:(f0 + n) * 2 * B], n, B, first + f0, rate)
+        for f in range(n):
+            rc, fb, _ = orc.encode_frame(oopts0, rate, bps, list(planar_frames(pcm, 2, B))[f0 + f], frame_number=first + f0 + f)
+            assert rc == 0 and data[off[f]:off[f + 1]] == fb, (grid, n, f0, f)
+    an.close()

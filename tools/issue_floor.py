@@ -199,6 +199,8 @@ def main():
         build_ids.add(v.get("_build_id"))
         return v[kernel]["SQ_INSTS_VALU"]
 
+    # config 3's collection: the newest one-letter tag of the round (r05_c, r05_d, ...), as bench.py picks it
+    c3 = sorted(f for f in os.listdir(prof) if re.match(rf"^{a.tag}_[a-z]_valu\.json$", f))[-1][:-len("_valu.json")]
     A = lambda f: os.path.join(a.asm_dir, f)   # noqa: E731
     out = {"costs_ns_per_wave_inst_per_simd_at_4_waves": cost,
            "method": __doc__.split("usage:")[0].strip()}
@@ -208,9 +210,9 @@ def main():
     ac = blocks_of(A("autocorr.gfx950.s"), "k_autocorr4ILi13ELi4ELb1ELb1ELi0ELb1")
     fr = blocks_of(A("frame64_d.gfx950.s"), "k_frame64ILi128ELi64ELi16ELb1")
     out["config3"] = {
-        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn(f"{T}_c", "k_cand64p"), 32768),
-        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(f"{T}_c", "k_autocorr4")),
-        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(f"{T}_c", "k_frame64")),
+        "k_cand64": floor("k_cand64p<64,16,true,true>", pick_cand(cd, 2, 2), cost, dyn(c3, "k_cand64p"), 32768),
+        "k_autocorr": floor("k_autocorr4<13,4,true,true,0,true>", pick_loops(ac), cost, dyn(c3, "k_autocorr4")),
+        "k_pack": floor("k_frame64<128,64,16,true>", fr, cost, dyn(c3, "k_frame64")),
     }
     # config 3 on the high-order input: orders 8..12 win (10 taps as the representative instantiation)
     out["config3hi"] = {
