@@ -112,14 +112,14 @@ struct Params {
     // check_fir = 1 (resolve_order_ties), where every candidate takes the exact read-only test fir64_overflows first.
     uint32_t check_fir;
     uint32_t fir_suspect_bits;   // 30; a TEST knob lowers it so that ordinary input exercises the re-run
-    // The exact FIXED bit count (encode.rs:3898-3907 for the FIXED residual) put off until the LPC candidate's size is
-    // known (k_cand64p, direct stereo input) -- r05.  The partition search of the FIXED residual needs only the leaf sums
-    // the order statistics hold; from the same sums a LOWER BOUND of its exact size follows (per Rice partition
-    // sum (u >> k) >= ceil(2 S / 2^k) - count).  When k_lpc's size estimate of the LPC candidate (LpcParams::est8, 1/8 bit
-    // per sample) undercuts that bound by defer_margin16 / 16 bit per sample, the wave runs the LPC half first; an exact
-    // lpc_bits < bound then DECIDES encode.rs:2929-2934 for LPC without the FIXED count, otherwise the wave re-fetches its
-    // samples and counts after all.  0: never (A/B), 1: by the estimate, 2: whenever LPC parameters exist (TEST: every
-    // undecided candidate takes the re-fetch).  defer_stats: {waves that deferred, of those: re-fetched}, cumulative.
+    // The FIXED half's partition tree and exact bit count (encode.rs:3862-3947 for the FIXED residual) put off until the LPC
+    // candidate's size is known (k_cand64p, direct stereo input) -- r05.  From the 64 leaf sums the order statistics hold a
+    // LOWER BOUND of the FIXED residual block's size follows at any partition order (wave_cand_fixed.inc).  When k_lpc's size
+    // estimate of the LPC candidate (LpcParams::est8, 1/8 bit per sample) undercuts that bound by defer_margin16 / 16 bit per
+    // sample, the wave runs the LPC half first; an exact lpc_bits < bound then DECIDES encode.rs:2929-2934 for LPC without
+    // tree or count, otherwise the wave builds the tree, re-fetches its samples and counts after all.  0: never (A/B), 1: by
+    // the estimate, 2: whenever LPC parameters exist (TEST: every undecided candidate takes the re-fetch).
+    // defer_stats: {waves that deferred, of those: re-fetched}, cumulative.
     uint32_t defer_fixed, defer_margin16;
     uint32_t *defer_stats;   // [DEFER_SLOTS][DEFER_SLOT_WORDS]: the pair {deferred, re-fetched} per slot
     // k_cand64p's DYNAMIC TURNS (r05): the launch's ticket counter -- 0 when a launch begins (zeroed with the batch's

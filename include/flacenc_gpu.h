@@ -129,10 +129,10 @@ typedef struct {
                                    folded residuals >= 2^30: garbage predictions only) */
     uint32_t fir_rechecked;     /* of fir_recheck: re-analysed with the exact test before the results were handed
                                    out (the same entry points as order_ties_resolved) */
-    /* CUMULATIVE since the context was created (direct stereo input of 4096-sample blocks with LPC): candidates whose
-     * exact FIXED bit count was put off behind the LPC half because the LPC size estimate undercut a lower bound of the
+    /* CUMULATIVE since the context was created (direct stereo input with LPC): candidates whose FIXED partition search and
+     * exact bit count were put off behind the LPC half because the LPC size estimate undercut a lower bound of the
      * FIXED size -- fixed_decided: the exact LPC size then lay below the bound, encode.rs:2929-2934 was decided for LPC
-     * without the count; fixed_refetched: it did not, the samples were fetched again and counted.  Same bytes either way. */
+     * without them; fixed_refetched: it did not, the samples were fetched again and counted.  Same bytes either way. */
     uint32_t fixed_decided;
     uint32_t fixed_refetched;
 } flacgpu_stats;

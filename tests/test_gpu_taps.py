@@ -145,14 +145,13 @@ def test_bursts_that_make_the_predictor_run_wild(monkeypatch, bps, max_lpc, orde
         assert st.fir_recheck > 0, "this input is meant to reach the re-run"
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
 @pytest.mark.parametrize("max_lpc", [12, 32])
 def test_deferred_fixed_count_gives_the_same_bytes(monkeypatch, mode, max_lpc):
-    """Params::defer_fixed (r05): the exact FIXED bit count put off behind the LPC half and skipped where a lower bound of
-    the FIXED size already exceeds the exact LPC size (encode.rs:2929-2934), re-fetching the samples otherwise.  Never (0),
-    by the LPC estimate (1, the default), whenever LPC parameters exist (2: the re-fetch path for every undecided
-    candidate) and with the partition TREE put off as well behind the leaf-level bound (3: for every candidate with LPC
-    parameters; mode 1 does it where the estimate clears that bound) must all give the oracle's bytes; the counters show
+    """Params::defer_fixed (r05): the FIXED half's partition tree and exact bit count put off behind the LPC half and skipped
+    where a lower bound of the FIXED size (from the 64 leaf sums) already exceeds the exact LPC size (encode.rs:2929-2934);
+    the tree, a re-fetch of the samples and the count otherwise.  Never (0), by the LPC estimate (1, the default) and whenever
+    LPC parameters exist (2: the late path for every undecided candidate) must all give the oracle's bytes; the counters show
     which paths ran."""
     import ctypes as C
 
@@ -178,7 +177,7 @@ def test_deferred_fixed_count_gives_the_same_bytes(monkeypatch, mode, max_lpc):
     an.close()
     if mode == "0":
         assert st.fixed_decided == 0 and st.fixed_refetched == 0
-    elif mode == "2" or (mode == "3" and max_lpc > 16):   # (the leaf bound is built into the order-32 instantiation only)
+    elif mode == "2":
         assert st.fixed_decided > 0 and st.fixed_refetched > 0, (st.fixed_decided, st.fixed_refetched)
         assert st.fixed_decided + st.fixed_refetched <= 4 * n
     else:
