@@ -209,6 +209,8 @@ def _load():
     L.flacgpu_encode_segments_device.argtypes = [vp, C.POINTER(Segment), C.c_uint32, C.c_uint32, vp]
     L.flacgpu_encode_segments.argtypes = [vp, C.POINTER(Segment), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.flacgpu_encode_segments_packed_async_host.argtypes = [vp, C.c_void_p, C.c_uint32, C.POINTER(Segment), C.c_uint32,
+                                                            C.c_uint32, C.c_void_p, C.c_size_t]
     sc = C.POINTER(ShardCounters)
     u64p = C.POINTER(C.c_uint64)
     L.flacgpu_merge_counters.argtypes = [sc, C.c_uint32, sc, u64p]

@@ -748,6 +748,13 @@ static int ensure_planar(flacgpu_ctx *c) {
 static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
                         uint32_t last_len, hipStream_t st, uint32_t packed_bytes);
 
+// A batch that is NOT made of segments begins: the per-frame tables of an earlier flacgpu_encode_segments* batch on this
+// context (frame numbers, addresses, the segments ensure_planar would walk) must not reach its frame assembly or verifier.
+static void begin_plain_batch(flacgpu_ctx *c) {
+    c->seg_active = c->seg_pending = c->seg_direct = false;
+    c->segs.clear();
+}
+
 int flacgpu_analyze_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32_t n_frames,
                            uint32_t last_len, void *stream) {
     if (!c || !d_pcm) {
@@ -767,10 +774,15 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
         g_last_error = "invalid analyze arguments";
         return FLACGPU_ERR_INVALID_ARG;
     }
-    // (every batch passes here: one made of segments announces itself just before)
+    // (a batch made of segments announces itself just before; the entry points that start a batch WITHOUT passing here --
+    // the two-ranges branch of flacgpu_encode_device, flacgpu_pack_plans -- call begin_plain_batch themselves)
     if (c->rng_cnt == 0 || c->rng_f0 == 0) {
-        c->seg_active = c->seg_pending;
-        c->seg_pending = false;
+        if (c->seg_pending) {
+            c->seg_active = true;
+            c->seg_pending = false;
+        } else {
+            begin_plain_batch(c);
+        }
     }
     const uint32_t B = c->opts.block_size;
     // the reference collects partitions into ArrayVec<_, 64> and panics beyond (encode.rs:3880)
@@ -1338,6 +1350,7 @@ int flacgpu_encode_device(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint
         return pack_impl(c, first_frame_number, sample_rate, st0, nullptr);
     }
     hipStream_t st1 = c->aux_stream;
+    begin_plain_batch(c);   // (this branch never passes analyze_impl)
     Params p;
     fill_params(c, n_frames, last_len, p);
     PackParams q;
@@ -1425,7 +1438,10 @@ static int segments_common(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t
         HIP_TRY(hipMalloc((void **)&c->d_seg_ptr, sizeof(int32_t *) * F));
         HIP_TRY(hipHostMalloc((void **)&c->h_seg, sizeof(uint64_t) * 2 * F, hipHostMallocDefault));
     }
-    HIP_TRY(hipStreamSynchronize(st));   // (the staging arrays of the batch before are free)
+    // the staging arrays and the device tables of the batch before are free once BOTH streams are idle: the one this call
+    // runs on and the one the context's last batch (or its re-assembly after a host re-decision) was submitted to
+    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = ctx_sync(c)) return rc;
     const size_t frame_ints = (size_t)B * c->channels;
     Params probe;
     fill_params(c, (uint32_t)total, B, probe);
@@ -1451,7 +1467,10 @@ static int segments_common(flacgpu_ctx *c, const flacgpu_segment *segs, uint32_t
     c->seg_pending = true;
     c->seg_direct = direct;
     c->rng_f0 = c->rng_cnt = 0;
-    if (int rc = analyze_impl(c, direct ? segs[0].pcm : c->d_in, FLACGPU_LAYOUT_INTERLEAVED, (uint32_t)total, B, st, 0)) return rc;
+    if (int rc = analyze_impl(c, direct ? segs[0].pcm : c->d_in, FLACGPU_LAYOUT_INTERLEAVED, (uint32_t)total, B, st, 0)) {
+        c->seg_pending = false;   // (refused before the analysis took the announcement)
+        return rc;
+    }
     return pack_impl(c, segs[0].first_frame_number, sample_rate, st, nullptr);
 }
 
@@ -1536,6 +1555,7 @@ int flacgpu_pack_plans(flacgpu_ctx *c, const int32_t *pcm, uint32_t n_frames, ui
     }
     CTX_GUARD(c);
     hipStream_t st = c->own_stream;
+    begin_plain_batch(c);   // (no analyze_impl here)
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t count = ((size_t)(n_frames - 1) * B + last_len) * C;
     HIP_TRY(hipMemcpyAsync(c->d_in, pcm, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1885,6 +1905,9 @@ int flacgpu_device_count(void) {
 int flacgpu_packed_input_supported(const flacgpu_ctx *c, uint32_t bytes_per_sample) {
     return c && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample) ? 1 : 0;
 }
+int flacgpu_packed_input_shape_supported(uint32_t block_size, uint32_t channels, uint32_t bytes_per_sample) {
+    return packed_k0_supported(block_size, channels, bytes_per_sample) ? 1 : 0;
+}
 
 // record `ev` on `st` (the waits below are for it)
 static int record_waitable(flacgpu_ctx *, hipEvent_t ev, hipStream_t st) {
@@ -1916,17 +1939,73 @@ int flacgpu_encode_packed_async(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t 
                                             sample_rate, nullptr, 0);
 }
 
+static bool packed_async_args_ok(const flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample, uint64_t n_frames,
+                                 uint32_t last_len) {
+    return c && pcm_le && n_frames != 0 && n_frames <= c->max_frames && last_len != 0 && last_len <= c->opts.block_size &&
+           (bytes_per_sample == 4 ||
+            (bytes_per_sample == (c->bps + 7) / 8 && packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample)));
+}
+
+static int packed_async_impl(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample, uint32_t n_frames, uint32_t last_len,
+                             uint64_t first_frame_number, uint32_t sample_rate, uint8_t *out_host, size_t out_cap);
+
 int flacgpu_encode_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
                                      uint32_t n_frames, uint32_t last_len, uint64_t first_frame_number,
                                      uint32_t sample_rate, uint8_t *out_host, size_t out_cap) {
-    if (!c || !pcm_le || n_frames == 0 || n_frames > c->max_frames || last_len == 0 ||
-        last_len > c->opts.block_size ||
-        !(bytes_per_sample == 4 || (bytes_per_sample == (c->bps + 7) / 8 &&
-                                    packed_k0_supported(c->opts.block_size, c->channels, bytes_per_sample)))) {
+    if (!packed_async_args_ok(c, pcm_le, bytes_per_sample, n_frames, last_len)) {
         g_last_error = "flacgpu_encode_packed_async: invalid arguments / unsupported sample width for this stream shape";
         return FLACGPU_ERR_INVALID_ARG;
     }
     CTX_GUARD(c);
+    return packed_async_impl(c, pcm_le, bytes_per_sample, n_frames, last_len, first_frame_number, sample_rate, out_host, out_cap);
+}
+
+// The same with the batch made of SEGMENTS (frames of several streams, each numbered by its own stream): the segments' whole
+// blocks lie back to back in `pcm_le` (the caller packed them there: flacgpu_segment::pcm is not looked at), the frame numbers
+// reach the frame assembly through the per-frame table.
+int flacgpu_encode_segments_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                              const flacgpu_segment *segs, uint32_t n_segs, uint32_t sample_rate,
+                                              uint8_t *out_host, size_t out_cap) {
+    if (!c || !segs || n_segs == 0) return FLACGPU_ERR_INVALID_ARG;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_segs; i++) {
+        if (segs[i].n_frames == 0) {
+            g_last_error = "flacgpu_encode_segments_packed_async_host: an empty segment";
+            return FLACGPU_ERR_INVALID_ARG;
+        }
+        total += segs[i].n_frames;
+    }
+    if (!packed_async_args_ok(c, pcm_le, bytes_per_sample, total, c->opts.block_size)) {
+        g_last_error = "flacgpu_encode_segments_packed_async_host: invalid arguments / more frames than the context holds / "
+                       "unsupported sample width for this stream shape";
+        return FLACGPU_ERR_INVALID_ARG;
+    }
+    CTX_GUARD(c);
+    const size_t F = c->max_frames;
+    if (!c->d_seg_fn) {
+        HIP_TRY(hipMalloc((void **)&c->d_seg_fn, sizeof(uint64_t) * F));
+        HIP_TRY(hipMalloc((void **)&c->d_seg_ptr, sizeof(int32_t *) * F));
+        HIP_TRY(hipHostMalloc((void **)&c->h_seg, sizeof(uint64_t) * 2 * F, hipHostMallocDefault));
+    }
+    if (int rc = ctx_sync(c)) return rc;   // (the table's staging copy of the batch before is free; one batch per context at a time)
+    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    uint64_t *fn = c->h_seg;
+    uint32_t f = 0;
+    for (uint32_t i = 0; i < n_segs; i++)
+        for (uint32_t k = 0; k < segs[i].n_frames; k++) fn[f++] = segs[i].first_frame_number + k;
+    HIP_TRY(hipMemcpyAsync(c->d_seg_fn, fn, sizeof(uint64_t) * total, hipMemcpyHostToDevice, c->own_stream));
+    c->segs.clear();          // (nothing is read in place: the batch is one contiguous run of blocks in the context's input buffer)
+    c->seg_pending = true;
+    c->seg_direct = false;
+    c->rng_f0 = c->rng_cnt = 0;
+    const int rc = packed_async_impl(c, pcm_le, bytes_per_sample, (uint32_t)total, c->opts.block_size, segs[0].first_frame_number,
+                                     sample_rate, out_host, out_cap);
+    if (rc) c->seg_pending = false;   // (refused before the analysis took the announcement)
+    return rc;
+}
+
+static int packed_async_impl(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample, uint32_t n_frames, uint32_t last_len,
+                             uint64_t first_frame_number, uint32_t sample_rate, uint8_t *out_host, size_t out_cap) {
     hipStream_t st = c->own_stream;
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t bytes = ((size_t)(n_frames - 1) * B + last_len) * C * bytes_per_sample;
@@ -2210,11 +2289,13 @@ int flacgpu_get_stats(flacgpu_ctx *c, flacgpu_stats *out) {
     out->fir_rechecked = c->fir_rechecked;
     uint32_t d[kDeferWords];
     if (int rc = copy_sync(c, d, defer_stats_of(c), sizeof d, hipMemcpyDeviceToHost)) return rc;
-    out->fixed_decided = out->fixed_refetched = 0;
+    uint64_t decided = 0, refetched = 0;   // (64 counter lines of 32 bits each: summed wide, handed out saturated)
     for (uint32_t i = 0; i < DEFER_SLOTS; i++) {
-        out->fixed_decided += d[DEFER_SLOT_WORDS * i];
-        out->fixed_refetched += d[DEFER_SLOT_WORDS * i + 1];
+        decided += d[DEFER_SLOT_WORDS * i];
+        refetched += d[DEFER_SLOT_WORDS * i + 1];
     }
+    out->fixed_decided = (uint32_t)std::min<uint64_t>(decided, 0xFFFFFFFFull);
+    out->fixed_refetched = (uint32_t)std::min<uint64_t>(refetched, 0xFFFFFFFFull);
     return FLACGPU_OK;
 }
 

@@ -1,0 +1,612 @@
+// coalesce.cpp -- flacenc_encode_many_coalesced: many whole streams in host memory -> .flac bytes, the frames of all
+// streams of one shape travelling through ONE ring of pinned staging buffers at the link's rate.
+//
+// The reference opens an `Encoder` per file and walks its blocks one by one (encode.rs:487-627): a writer per stream gives
+// every stream batches of its own frames, each paying the kernels' launches and their serial walk over a block, and small
+// streams never fill the GPU.  Here (r06; r05's first form uploaded int32 from the callers' pageable buffers, one
+// synchronous batch per worker, and reached 0.09 of the link):
+//
+//   * batches are made of SEGMENTS -- runs of whole blocks of several streams, taken from the streams in turn so that all
+//     their MD5 chains advance together -- and every frame keeps its own stream's frame number
+//     (flacgpu_encode_segments_packed_async_host);
+//   * a ring of `depth` slots, each an analysis context with a pinned input and a pinned output buffer: the workers PACK the
+//     callers' int32 samples into the slot's input at stream width (2 or 3 bytes per sample across PCIe instead of 4; the
+//     packed bytes are update_md5's byte string, encode.rs:1292-1318, so the MD5 lanes hash them where they lie), the last
+//     packer SUBMITS the batch (upload, kernels and frame assembly queued, k_frame64 storing the frames straight into the
+//     slot's pinned output), one worker at a time RETIRES the oldest batch and the frames are COPIED to their places in the
+//     callers' output buffers (the only host copy of an output byte); a slot is reused once its upload, its frames and the
+//     MD5 runs that read its input are done.  Upload of batch i + 1, kernels of batch i and the frames of batch i - 1 are in
+//     flight together;
+//   * a stream's short last block is one synchronous one-frame call on a small context of its own kind; everything in front
+//     of the first frame is rebuilt from the frame sizes (flacenc_stream_header) -- the bytes Encoder::new / encode /
+//     finalize_inner leave (encode.rs:1882-2110), stream by stream.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "checksums.h"
+#include "host_internal.h"
+#include "md5_mb.h"
+
+using namespace flacenc;
+using namespace flacenc_host;
+
+namespace {
+
+// ---- ring slots, kept between calls (a context for 2048 stereo frames is a few hundred MB of device memory and tens of
+// milliseconds to create; pinning its staging buffers costs more) ------------------------------------------------------------
+struct RingSlot {
+    flacgpu_ctx *ctx = nullptr;
+    uint8_t *in = nullptr, *out = nullptr;   // pinned
+    size_t in_cap = 0, out_cap = 0;
+    size_t bytes() const { return in_cap + out_cap; }
+    void destroy() {
+        if (ctx) flacgpu_destroy(ctx);
+        flacgpu_host_free(in);
+        flacgpu_host_free(out);
+        ctx = nullptr;
+        in = out = nullptr;
+    }
+};
+struct RingKey {
+    flacgpu_options g;
+    uint32_t bps, ch, frames;
+    int device;
+    bool operator==(const RingKey &k) const {   // field by field: the structs carry padding
+        return g.block_size == k.g.block_size && g.max_partition_order == k.g.max_partition_order &&
+               g.max_lpc_order == k.g.max_lpc_order && g.mid_side == k.g.mid_side &&
+               g.exhaustive_channel_correlation == k.g.exhaustive_channel_correlation && g.window_kind == k.g.window_kind &&
+               g.window_param == k.g.window_param && bps == k.bps && ch == k.ch && frames == k.frames && device == k.device;
+    }
+};
+struct RingPool {
+    static constexpr size_t kIdleBytes = size_t(1) << 30;   // pinned bytes kept idle
+    static constexpr size_t kIdleSlots = 12;
+    std::mutex mu;
+    std::vector<std::pair<RingKey, RingSlot>> idle;
+    static RingPool &get() {
+        static RingPool *p = new RingPool();   // leaked on purpose: no HIP calls during static destruction
+        return *p;
+    }
+    int take(const RingKey &k, size_t in_bytes, RingSlot *s) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].first == k && idle[i].second.in_cap >= in_bytes) {
+                    *s = idle[i].second;
+                    idle.erase(idle.begin() + (ptrdiff_t)i);
+                    return 0;
+                }
+        }
+        int rc = flacgpu_create(&k.g, k.bps, k.ch, k.device, k.frames, &s->ctx);
+        if (rc) return rc;
+        s->out_cap = flacgpu_packed_cap(s->ctx);
+        s->out = static_cast<uint8_t *>(flacgpu_host_alloc(s->out_cap));
+        s->in_cap = in_bytes + 64;
+        s->in = static_cast<uint8_t *>(flacgpu_host_alloc(s->in_cap));
+        if (!s->out || !s->in) {
+            s->destroy();
+            return FLACGPU_ERR_HIP;
+        }
+        return 0;
+    }
+    void give(const RingKey &k, const RingSlot &s) {
+        std::vector<RingSlot> drop;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            idle.emplace_back(k, s);
+            size_t total = 0;
+            for (auto &e : idle) total += e.second.bytes();
+            while (idle.size() > 1 && (idle.size() > kIdleSlots || total > kIdleBytes)) {   // the oldest go
+                total -= idle.front().second.bytes();
+                drop.push_back(idle.front().second);
+                idle.erase(idle.begin());
+            }
+        }
+        for (auto &d : drop) d.destroy();
+    }
+    void release_all() {
+        std::vector<std::pair<RingKey, RingSlot>> all;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            all.swap(idle);
+        }
+        for (auto &e : all) e.second.destroy();
+    }
+};
+
+struct Stream {
+    size_t job = 0;
+    uint64_t pcm_frames = 0, whole = 0;   // samples per channel, whole blocks
+    uint32_t tail = 0;                    // samples of the short last block (0: none)
+    size_t hlen = 0;                      // bytes in front of the first frame
+    std::vector<uint32_t> sizes;          // per frame
+    uint64_t pos = 0;                     // bytes of the frames placed so far (retired in stream order)
+    std::vector<uint8_t> tail_bytes;      // the short last block's frame
+    std::vector<uint8_t> tail_le;         // ... and its samples as update_md5's bytes
+    std::vector<uint8_t> le;              // the whole byte string, only when the upload cannot take the stream's width
+    Md5 md5;
+    Md5Lane *lane = nullptr;
+    // MD5 runs are pushed in stream order whatever the order the packers finish in
+    std::mutex mu;
+    uint64_t next_md5_frame = 0;
+    struct Pending {
+        const uint8_t *p;
+        size_t n;
+        uint32_t frames;
+        std::atomic<uint64_t> *ticket;
+    };
+    std::map<uint64_t, Pending> pending;
+    uint64_t last_ticket = 0;
+};
+
+struct Seg {
+    size_t stream;
+    uint64_t first;   // first frame (block index in its stream)
+    uint32_t n, boff; // frames, frame offset inside the batch
+    std::atomic<uint64_t> ticket{0};   // of its MD5 run (0: not pushed yet)
+    Seg(size_t s, uint64_t f, uint32_t n_, uint32_t b) : stream(s), first(f), n(n_), boff(b) {}
+    Seg(const Seg &o) : stream(o.stream), first(o.first), n(o.n), boff(o.boff), ticket(o.ticket.load()) {}
+};
+struct Batch {
+    std::vector<Seg> segs;
+    uint32_t frames = 0;
+    int slot = -1;
+    std::atomic<uint32_t> pack_left{0}, copy_left{0};
+    bool submitted = false, failed = false;
+    Batch() = default;
+    Batch(Batch &&o) noexcept : segs(std::move(o.segs)), frames(o.frames), slot(o.slot), submitted(o.submitted), failed(o.failed) {}
+};
+struct CopyJob {
+    const uint8_t *src;
+    uint8_t *dst;
+    size_t n;
+};
+struct Task {
+    enum Kind { NONE, PACK, COPY, RETIRE, TAIL } kind = NONE;
+    size_t batch = 0, i0 = 0, i1 = 0;   // PACK: segments [i0, i1) of the batch; COPY: copy jobs [i0, i1); TAIL: stream i0
+};
+
+}  // namespace
+
+extern "C" {
+
+void flacenc_release_pools(void) {
+    RingPool::get().release_all();
+    release_lane_pool();
+}
+
+int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
+    if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
+    if (int e = options_error(*opts_in)) return e;
+    const flacenc_options &o = *opts_in;
+    const uint32_t B = o.block_size;
+    struct Shape {
+        uint32_t rate, bps, ch;
+        bool operator<(const Shape &k) const { return std::tie(rate, bps, ch) < std::tie(k.rate, k.bps, k.ch); }
+    };
+    std::map<Shape, std::vector<size_t>> groups;
+    std::vector<std::unique_ptr<Stream>> st(n_jobs);
+    const double t_begin = now_ms();
+    for (size_t i = 0; i < n_jobs; i++) {
+        flacenc_job &j = jobs[i];
+        j.out_len = 0;
+        j.status = 0;
+        j.start_ms = j.elapsed_ms = j.pack_ms = j.gpu_ms = j.md5_ms = 0.0;
+        if (!j.samples || !j.out || j.bits_per_sample < 1 || j.bits_per_sample > 32 || j.channels == 0 || j.channels > 8 ||
+            j.count % j.channels || j.count == 0) {
+            j.status = FLACENC_ERR_INVALID_ARG;
+            continue;
+        }
+        size_t hlen = 0;
+        if (int rc = stream_header_len(o, j.sample_rate, j.bits_per_sample, j.channels, j.count / j.channels, &hlen)) {
+            j.status = rc;
+            continue;
+        }
+        st[i].reset(new Stream());
+        Stream &s = *st[i];
+        s.job = i;
+        s.hlen = hlen;
+        s.pcm_frames = j.count / j.channels;
+        s.whole = s.pcm_frames / B;
+        s.tail = (uint32_t)(s.pcm_frames % B);
+        s.sizes.assign(s.whole + (s.tail ? 1 : 0), 0);
+        groups[Shape{j.sample_rate, j.bits_per_sample, j.channels}].push_back(i);
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = std::max(1u, std::min<unsigned>(threads ? threads : std::min(hw / 2 ? hw / 2 : 1u, 12u), 64u));
+    std::mutex err_mu;
+    auto fail = [&](size_t job, int rc) {
+        std::lock_guard<std::mutex> l(err_mu);
+        if (!jobs[job].status) jobs[job].status = rc;
+    };
+    auto has_failed = [&](size_t job) {
+        std::lock_guard<std::mutex> l(err_mu);
+        return jobs[job].status != 0;
+    };
+    const int device = o.device >= 0 ? o.device : flacgpu_current_device();
+
+    for (auto &kv : groups) {
+        const Shape sh = kv.first;
+        const std::vector<size_t> &ids = kv.second;
+        const unsigned width = (sh.bps + 7) / 8;
+        const unsigned up_width = (width < 4 && flacgpu_packed_input_shape_supported(B, sh.ch, width)) ? width : 4u;
+        const size_t per = (size_t)B * sh.ch;
+        const flacgpu_options g = gpu_options(o, B);
+
+        // ---- batches: about 16 Mi samples each, the streams taken in turn, a quantum of whole blocks at a time
+        uint64_t total_whole = 0;
+        size_t n_active = 0;
+        for (size_t i : ids) {
+            total_whole += st[i]->whole;
+            n_active += st[i]->whole ? 1 : 0;
+        }
+        uint32_t batch_cap = o.batch_frames ? std::max(o.batch_frames, 64u) : (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(64, (16u << 20) / per));
+        batch_cap = (uint32_t)std::min<uint64_t>(batch_cap, std::max<uint64_t>(total_whole, 1));
+        std::vector<Batch> batches;
+        {
+            std::vector<uint64_t> done(n_jobs, 0);
+            std::deque<size_t> active;
+            for (size_t i : ids)
+                if (st[i]->whole) active.push_back(i);
+            while (!active.empty()) {
+                Batch b;
+                // a quantum that lets a batch visit every active stream, but no less than 8 blocks (a stream of a few blocks goes whole)
+                const uint32_t q = std::max<uint32_t>(8u, (uint32_t)((batch_cap + active.size() - 1) / active.size()));
+                while (b.frames < batch_cap && !active.empty()) {
+                    const size_t i = active.front();
+                    active.pop_front();
+                    const uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(q, st[i]->whole - done[i]), batch_cap - b.frames);
+                    b.segs.emplace_back(i, done[i], n, b.frames);
+                    b.frames += n;
+                    done[i] += n;
+                    if (done[i] < st[i]->whole) active.push_back(i);
+                }
+                batches.push_back(std::move(b));
+            }
+        }
+        std::vector<size_t> tails;
+        for (size_t i : ids)
+            if (st[i]->tail) tails.push_back(i);
+
+        // ---- the ring
+        const RingKey key{g, sh.bps, sh.ch, batch_cap, device};
+        const RingKey tail_key{g, sh.bps, sh.ch, 1u, device};
+        const size_t in_bytes = (size_t)batch_cap * per * up_width;
+        const unsigned depth = (unsigned)std::min<size_t>(std::max<size_t>(batches.size(), 1), o.pipeline_depth ? std::min<uint32_t>(o.pipeline_depth, 8u) : 4u);
+        std::vector<RingSlot> slots;
+        int ring_rc = 0;
+        for (unsigned d = 0; d < depth && !batches.empty(); d++) {
+            RingSlot s;
+            const int rc = RingPool::get().take(key, in_bytes, &s);
+            if (rc) {
+                ring_rc = rc;
+                break;
+            }
+            slots.push_back(s);
+        }
+        if (slots.empty() && !batches.empty()) {   // no context at all: every stream of the group fails
+            for (size_t i : ids) fail(i, ring_rc == FLACGPU_ERR_UNSUPPORTED ? FLACENC_ERR_UNSUPPORTED : FLACENC_ERR_GPU);
+            continue;
+        }
+
+        // ---- scheduler state
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Task> copyq, packq, tailq;
+        std::vector<int> free_slots;
+        for (int d = (int)slots.size() - 1; d >= 0; d--) free_slots.push_back(d);
+        size_t next_assign = 0, retire_next = 0, batches_done = 0, tails_left = tails.size();
+        bool retiring = false;
+        std::vector<std::vector<CopyJob>> copy_jobs(batches.size());
+        for (size_t t : tails) {
+            Task k;
+            k.kind = Task::TAIL;
+            k.i0 = t;
+            tailq.push_back(k);
+        }
+        // (mu held) hand the free slots to the next batches and queue their packing, a few segments per task
+        auto assign = [&]() {
+            while (!free_slots.empty() && next_assign < batches.size()) {
+                Batch &b = batches[next_assign];
+                b.slot = free_slots.back();
+                free_slots.pop_back();
+                const size_t ns = b.segs.size();
+                size_t i0 = 0;
+                uint32_t ntasks = 0;
+                std::vector<Task> ts;
+                while (i0 < ns) {   // ~128 frames of packing per task
+                    size_t i1 = i0;
+                    uint32_t fr = 0;
+                    while (i1 < ns && fr < 128) fr += b.segs[i1++].n;
+                    Task k;
+                    k.kind = Task::PACK;
+                    k.batch = next_assign;
+                    k.i0 = i0;
+                    k.i1 = i1;
+                    ts.push_back(k);
+                    ntasks++;
+                    i0 = i1;
+                }
+                b.pack_left.store(ntasks);
+                for (auto &k : ts) packq.push_back(k);
+                next_assign++;
+            }
+        };
+        // a stream's MD5 runs in stream order: a segment packed ahead of its predecessors waits in the stream's list
+        auto md5_push = [&](Stream &s, uint64_t first, uint32_t frames, const uint8_t *p, size_t n, std::atomic<uint64_t> *ticket) {
+            std::lock_guard<std::mutex> l(s.mu);
+            if (!s.lane) {   // (no engine lane: hash here, in order all the same)
+                s.pending.emplace(first, Stream::Pending{p, n, frames, ticket});
+                for (auto it = s.pending.begin(); it != s.pending.end() && it->first == s.next_md5_frame; it = s.pending.erase(it)) {
+                    s.md5.update(it->second.p, it->second.n);
+                    s.next_md5_frame += it->second.frames;
+                    if (it->second.ticket) it->second.ticket->store(~0ull, std::memory_order_release);
+                }
+                return;
+            }
+            s.pending.emplace(first, Stream::Pending{p, n, frames, ticket});
+            for (auto it = s.pending.begin(); it != s.pending.end() && it->first == s.next_md5_frame; it = s.pending.erase(it)) {
+                s.last_ticket = Md5Pool::get().push(s.lane, it->second.p, it->second.n);
+                s.next_md5_frame += it->second.frames;
+                if (it->second.ticket) it->second.ticket->store(s.last_ticket, std::memory_order_release);
+            }
+        };
+        auto run_pack = [&](const Task &k) {
+            Batch &b = batches[k.batch];
+            RingSlot &slot = slots[(size_t)b.slot];
+            const double t0 = now_ms();
+            for (size_t i = k.i0; i < k.i1; i++) {
+                Seg &sg = b.segs[i];
+                Stream &s = *st[sg.stream];
+                const flacenc_job &j = jobs[s.job];
+                const int32_t *src = j.samples + sg.first * per;
+                const size_t count = (size_t)sg.n * per;
+                uint8_t *dst = slot.in + (size_t)sg.boff * per * up_width;
+                if (up_width == width) {
+                    pack_le(src, count, width, dst);
+                    md5_push(s, sg.first, sg.n, dst, count * width, &sg.ticket);
+                } else {   // the upload takes int32 only: the MD5 bytes are packed beside it, into the stream's own string
+                    std::memcpy(dst, src, count * 4);
+                    uint8_t *le = s.le.data() + sg.first * per * width;
+                    pack_le(src, count, width, le);
+                    md5_push(s, sg.first, sg.n, le, count * width, nullptr);
+                    sg.ticket.store(~0ull, std::memory_order_release);   // (the slot's input is not what the MD5 reads)
+                }
+            }
+            const double dt = now_ms() - t0;
+            for (size_t i = k.i0; i < k.i1; i++) {
+                Stream &s = *st[b.segs[i].stream];
+                std::lock_guard<std::mutex> l(s.mu);
+                jobs[s.job].pack_ms += dt / (double)(k.i1 - k.i0);
+            }
+            if (b.pack_left.fetch_sub(1) != 1) return;
+            // the last packer of the batch submits it
+            std::vector<flacgpu_segment> gs(b.segs.size());
+            for (size_t i = 0; i < b.segs.size(); i++) {
+                gs[i].pcm = nullptr;
+                gs[i].n_frames = b.segs[i].n;
+                gs[i].reserved = 0;
+                gs[i].first_frame_number = b.segs[i].first;
+            }
+            const int rc = flacgpu_encode_segments_packed_async_host(slot.ctx, slot.in, up_width, gs.data(), (uint32_t)gs.size(), sh.rate,
+                                                                     slot.out, slot.out_cap);
+            {
+                std::lock_guard<std::mutex> l(mu);
+                b.failed = rc != 0;
+                b.submitted = true;
+            }
+            cv.notify_all();
+        };
+        // (any thread) the batch's frames are in their places: its slot is free once the MD5 runs that read its input are done
+        auto release_slot = [&](size_t bi) {
+            Batch &b = batches[bi];
+            for (Seg &sg : b.segs) {
+                uint64_t t;
+                while ((t = sg.ticket.load(std::memory_order_acquire)) == 0) std::this_thread::yield();   // (pushed by now: every earlier batch is packed)
+                Stream &s = *st[sg.stream];
+                if (t != ~0ull && s.lane) Md5Pool::get().wait(s.lane, t);
+            }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                free_slots.push_back(b.slot);
+                batches_done++;
+                assign();
+            }
+            cv.notify_all();
+        };
+        auto run_retire = [&](size_t bi) {
+            Batch &b = batches[bi];
+            RingSlot &slot = slots[(size_t)b.slot];
+            const double t0 = now_ms();
+            const uint64_t *off = nullptr;
+            uint64_t total = 0;
+            int rc = b.failed ? FLACGPU_ERR_HIP : flacgpu_frames_ready(slot.ctx, &off, &total);
+            if (!rc) rc = flacgpu_fetch_frames_async(slot.ctx, slot.out, slot.out_cap);   // (nothing to copy when k_frame64 stored them there)
+            if (!rc) rc = flacgpu_wait(slot.ctx);
+            else if (!b.failed) (void)flacgpu_wait(slot.ctx);
+            const double dt = now_ms() - t0;
+            std::vector<CopyJob> &cj = copy_jobs[bi];
+            uint32_t f = 0;
+            for (Seg &sg : b.segs) {
+                Stream &s = *st[sg.stream];
+                flacenc_job &j = jobs[s.job];
+                if (rc) {
+                    fail(s.job, FLACENC_ERR_GPU);
+                } else {
+                    const uint64_t bytes = off[f + sg.n] - off[f];
+                    for (uint32_t k = 0; k < sg.n; k++) s.sizes[sg.first + k] = (uint32_t)(off[f + k + 1] - off[f + k]);
+                    if (s.hlen + s.pos + bytes > j.out_cap) {
+                        fail(s.job, FLACENC_ERR_IO);
+                    } else if (!has_failed(s.job)) {
+                        cj.push_back(CopyJob{slot.out + off[f], j.out + s.hlen + s.pos, (size_t)bytes});
+                    }
+                    s.pos += bytes;
+                    j.gpu_ms += dt * sg.n / (double)b.frames;
+                }
+                f += sg.n;
+            }
+            // ~1 MB of frames per copy task
+            std::vector<Task> ts;
+            size_t i0 = 0;
+            while (i0 < cj.size()) {
+                size_t i1 = i0, bytes = 0;
+                while (i1 < cj.size() && bytes < (size_t(1) << 20)) bytes += cj[i1++].n;
+                Task k;
+                k.kind = Task::COPY;
+                k.batch = bi;
+                k.i0 = i0;
+                k.i1 = i1;
+                ts.push_back(k);
+                i0 = i1;
+            }
+            b.copy_left.store((uint32_t)ts.size());
+            {
+                std::lock_guard<std::mutex> l(mu);
+                for (auto &k : ts) copyq.push_back(k);
+                retiring = false;
+                retire_next++;
+            }
+            cv.notify_all();
+            if (ts.empty()) release_slot(bi);
+        };
+        auto run_copy = [&](const Task &k) {
+            const std::vector<CopyJob> &cj = copy_jobs[k.batch];
+            for (size_t i = k.i0; i < k.i1; i++) std::memcpy(cj[i].dst, cj[i].src, cj[i].n);
+            if (batches[k.batch].copy_left.fetch_sub(1) == 1) release_slot(k.batch);
+        };
+        // a stream's short last block: one frame, synchronously, on a one-frame context (one per worker that meets a tail)
+        auto run_tail = [&](size_t id, RingSlot &tslot, bool &have) {
+            Stream &s = *st[id];
+            const flacenc_job &j = jobs[s.job];
+            const int32_t *src = j.samples + s.whole * per;
+            const size_t count = (size_t)s.tail * sh.ch;
+            s.tail_le.resize(count * width);
+            pack_le(src, count, width, s.tail_le.data());
+            md5_push(s, s.whole, 1, s.tail_le.data(), s.tail_le.size(), nullptr);
+            int rc = 0;
+            if (!have) {
+                rc = RingPool::get().take(tail_key, per * 4, &tslot);
+                have = rc == 0;
+            }
+            uint64_t total = 0, off2[2] = {0, 0};
+            if (!rc)
+                rc = flacgpu_encode_frames(tslot.ctx, src, FLACGPU_LAYOUT_INTERLEAVED, 1, s.tail, s.whole, sh.rate, tslot.out, tslot.out_cap,
+                                           off2, &total);
+            if (rc) {
+                fail(s.job, FLACENC_ERR_GPU);
+            } else {
+                s.sizes[s.whole] = (uint32_t)total;
+                s.tail_bytes.assign(tslot.out, tslot.out + total);
+            }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                tails_left--;
+            }
+            cv.notify_all();
+        };
+
+        // ---- MD5 lanes first (every chain is attached before its first run arrives), then the workers
+        for (size_t i : ids) {
+            Stream &s = *st[i];
+            s.lane = Md5Pool::get().attach(&s.md5);
+            if (up_width != width) s.le.resize((size_t)s.whole * per * width);
+        }
+        {
+            std::lock_guard<std::mutex> l(mu);
+            assign();
+        }
+        auto work = [&]() {
+            RingSlot tslot;
+            bool have_tslot = false;
+            for (;;) {
+                Task k;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    for (;;) {
+                        if (!copyq.empty()) {
+                            k = copyq.front();
+                            copyq.pop_front();
+                            break;
+                        }
+                        if (!packq.empty()) {
+                            k = packq.front();
+                            packq.pop_front();
+                            break;
+                        }
+                        if (!retiring && retire_next < batches.size() && batches[retire_next].submitted) {
+                            retiring = true;
+                            k.kind = Task::RETIRE;
+                            k.batch = retire_next;
+                            break;
+                        }
+                        if (!tailq.empty()) {
+                            k = tailq.front();
+                            tailq.pop_front();
+                            break;
+                        }
+                        if (batches_done == batches.size() && tails_left == 0) {
+                            k.kind = Task::NONE;
+                            break;
+                        }
+                        cv.wait(lk);
+                    }
+                }
+                if (k.kind == Task::NONE) break;
+                if (k.kind == Task::PACK) run_pack(k);
+                else if (k.kind == Task::COPY) run_copy(k);
+                else if (k.kind == Task::RETIRE) run_retire(k.batch);
+                else run_tail(k.i0, tslot, have_tslot);
+            }
+            if (have_tslot) RingPool::get().give(tail_key, tslot);
+        };
+        const unsigned workers = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, total_whole / 64 + tails.size() + 1));
+        run_parallel(workers - 1, work);
+        for (auto &s : slots) RingPool::get().give(key, s);
+
+        // ---- finish: digest, metadata from the frame sizes, the tail frame behind the whole blocks' frames
+        std::atomic<size_t> next_fin{0};
+        auto finish = [&]() {
+            for (size_t k; (k = next_fin.fetch_add(1)) < ids.size();) {
+                Stream &s = *st[ids[k]];
+                flacenc_job &j = jobs[s.job];
+                if (s.lane) {
+                    Md5Pool::get().wait(s.lane, s.last_ticket);   // the whole chain
+                    j.md5_ms = Md5Pool::get().busy_ms(s.lane);
+                    Md5Pool::get().detach(s.lane);
+                    s.lane = nullptr;
+                }
+                if (j.status) continue;
+                uint8_t digest[16];
+                s.md5.digest(digest);
+                size_t hlen = 0;
+                const uint32_t last_len = s.tail ? s.tail : B;
+                int rc = flacenc_stream_header(&o, sh.rate, sh.bps, sh.ch, s.pcm_frames, digest, s.sizes.size(), s.sizes.data(), last_len,
+                                               j.out, j.out_cap, &hlen);
+                if (!rc && hlen != s.hlen) rc = FLACENC_ERR_IO;   // (cannot happen: the header's size is fixed at `new`)
+                if (rc || s.hlen + s.pos + s.tail_bytes.size() > j.out_cap) {
+                    j.status = rc && rc != FLACENC_ERR_INVALID_ARG ? rc : FLACENC_ERR_IO;
+                    continue;
+                }
+                if (!s.tail_bytes.empty()) std::memcpy(j.out + s.hlen + s.pos, s.tail_bytes.data(), s.tail_bytes.size());
+                j.out_len = s.hlen + s.pos + s.tail_bytes.size();
+                j.elapsed_ms = now_ms() - t_begin;
+            }
+        };
+        run_parallel((unsigned)std::min<size_t>(nt, std::max<size_t>(1, ids.size() / 16)) - 1, finish);
+    }
+    int first_error = 0;
+    for (size_t i = 0; i < n_jobs; i++)
+        if (jobs[i].status && !first_error) first_error = jobs[i].status;
+    return first_error;
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@
 #include "bitsink.h"
 #include "checksums.h"
 #include "md5_mb.h"
+#include "host_internal.h"
 #include "flacenc_gpu.h"
 #include "flacenc_stream.h"
 #include "frame_pack.h"
@@ -1437,294 +1438,7 @@ int flacenc_encode_many_devices(const flacenc_options *opts_in, flacenc_job *job
     return 0;
 }
 
-// ---- many SMALL streams: their frames coalesced into shared analysis batches ---------------------
-// flacenc_encode_many gives every stream a writer of its own: batches of the stream's own frames, each paying the kernels'
-// launches and their serial walk over a block -- a 256-frame batch runs at 0.3 of the per-sample rate of 8192 frames.
-// Here the streams of one shape share batches: runs of whole blocks of several streams make one
-// flacgpu_encode_segments call (every frame with its own stream's frame number), a stream's short last block goes
-// through a one-frame call, its MD5 chain runs on the shared multi-stream engines over the whole byte string, and
-// everything in front of the first frame is rebuilt from the frame sizes (flacenc_stream_header) -- the same bytes
-// Encoder::new / encode / finalize_inner leave (encode.rs:1882-2110), stream by stream.
-namespace {
-// contexts of the coalescing front end, kept between calls (creating one sized for 8192 frames allocates ~1.5 GB of device
-// memory and costs ~100 ms: more than a whole call of 256 small streams), with their pinned output staging
-struct CoalesceSlot {
-    flacgpu_ctx *ctx = nullptr;
-    uint8_t *out = nullptr;      // pinned, flacgpu_packed_cap(ctx) bytes
-    size_t cap = 0;
-};
-struct CoalesceKey {
-    flacgpu_options g;
-    uint32_t bps, ch, frames;
-    int device;
-    bool operator==(const CoalesceKey &k) const {
-        return std::memcmp(&g, &k.g, sizeof g) == 0 && bps == k.bps && ch == k.ch && frames == k.frames && device == k.device;
-    }
-};
-struct CoalescePool {
-    std::mutex mu;
-    std::vector<std::pair<CoalesceKey, CoalesceSlot>> idle;
-    static CoalescePool &get() {
-        static CoalescePool *p = new CoalescePool();
-        return *p;
-    }
-    int take(const CoalesceKey &k, CoalesceSlot *s) {
-        {
-            std::lock_guard<std::mutex> l(mu);
-            for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i].first == k) {
-                    *s = idle[i].second;
-                    idle.erase(idle.begin() + i);
-                    return 0;
-                }
-        }
-        int rc = flacgpu_create(&k.g, k.bps, k.ch, k.device, k.frames, &s->ctx);
-        if (rc) return rc;
-        s->cap = flacgpu_packed_cap(s->ctx);
-        s->out = static_cast<uint8_t *>(flacgpu_host_alloc(s->cap));
-        if (!s->out) {
-            flacgpu_destroy(s->ctx);
-            s->ctx = nullptr;
-            return FLACGPU_ERR_HIP;
-        }
-        return 0;
-    }
-    void give(const CoalesceKey &k, const CoalesceSlot &s) {
-        CoalesceSlot drop;
-        {
-            std::lock_guard<std::mutex> l(mu);
-            idle.emplace_back(k, s);
-            if (idle.size() > 8) {   // the oldest goes
-                drop = idle.front().second;
-                idle.erase(idle.begin());
-            }
-        }
-        if (drop.ctx) {
-            flacgpu_destroy(drop.ctx);
-            flacgpu_host_free(drop.out);
-        }
-    }
-};
-}  // namespace
-
-int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *jobs, size_t n_jobs, uint32_t threads) {
-    if (!opts_in || (!jobs && n_jobs)) return FLACENC_ERR_INVALID_ARG;
-    if (int e = options_error(*opts_in)) return e;
-    const flacenc_options &o = *opts_in;
-    const uint32_t B = o.block_size;
-    struct Stream {
-        size_t job;
-        uint64_t pcm_frames, whole;          // samples per channel, whole blocks
-        uint32_t tail;                       // samples of the short last block (0: none)
-        std::vector<uint32_t> sizes;         // per frame
-        std::vector<std::pair<uint64_t, std::vector<uint8_t>>> chunks;   // (first frame, bytes) as batches finish
-        std::vector<uint8_t> le;             // update_md5's byte string (encode.rs:1292-1318)
-        Md5 md5;
-        Md5Lane *lane = nullptr;
-        uint64_t md5_ticket = 0;
-        std::mutex mu;
-    };
-    struct Shape {
-        uint32_t rate, bps, ch;
-        bool operator<(const Shape &k) const { return std::tie(rate, bps, ch) < std::tie(k.rate, k.bps, k.ch); }
-    };
-    std::map<Shape, std::vector<size_t>> groups;
-    std::vector<std::unique_ptr<Stream>> st(n_jobs);
-    const double t_begin = now_ms();
-    for (size_t i = 0; i < n_jobs; i++) {
-        flacenc_job &j = jobs[i];
-        j.out_len = 0;
-        j.status = 0;
-        j.start_ms = j.elapsed_ms = j.pack_ms = j.gpu_ms = j.md5_ms = 0.0;
-        if (!j.samples || !j.out || j.bits_per_sample < 1 || j.bits_per_sample > 32 || j.channels == 0 ||
-            j.channels > 8 || j.count % j.channels || j.count == 0) {
-            j.status = FLACENC_ERR_INVALID_ARG;
-            continue;
-        }
-        {   // the checks of FlacSampleWriter::new / Encoder::new (sample rate, totals): a header-only writer runs them
-            flacenc_writer w;
-            w.header_only = true;
-            const int rc = w.init(o, j.sample_rate, j.bits_per_sample, j.channels, true, j.count / j.channels, nullptr);
-            w.finalized = true;   // (nothing to flush: the destructor must not try)
-            if (rc) {
-                j.status = rc;
-                continue;
-            }
-        }
-        st[i].reset(new Stream());
-        Stream &s = *st[i];
-        s.job = i;
-        s.pcm_frames = j.count / j.channels;
-        s.whole = s.pcm_frames / B;
-        s.tail = (uint32_t)(s.pcm_frames % B);
-        s.sizes.assign(s.whole + (s.tail ? 1 : 0), 0);
-        groups[Shape{j.sample_rate, j.bits_per_sample, j.channels}].push_back(i);
-    }
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = std::max(1u, std::min<unsigned>(threads ? threads : std::min(hw / 2 ? hw / 2 : 1u, 16u), 64u));
-    int first_error = 0;
-    std::mutex err_mu;
-    auto fail = [&](size_t job, int rc) {
-        std::lock_guard<std::mutex> l(err_mu);
-        if (!jobs[job].status) jobs[job].status = rc;
-    };
-    for (auto &kv : groups) {
-        const Shape sh = kv.first;
-        const std::vector<size_t> &ids = kv.second;
-        const unsigned width = (sh.bps + 7) / 8;
-        const size_t per = (size_t)B * sh.ch;
-        // ---- batches: segments of <= seg_cap frames taken from the streams in turn
-        uint64_t total_whole = 0;
-        for (size_t i : ids) total_whole += st[i]->whole;
-        const uint32_t batch_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(total_whole, 1), o.batch_frames ? std::max(o.batch_frames, 1024u) : 8192u);
-        struct Seg { size_t stream; uint64_t first; uint32_t n; };
-        std::vector<std::vector<Seg>> batches;
-        {
-            std::vector<Seg> cur;
-            uint32_t used = 0;
-            for (size_t i : ids) {
-                uint64_t done = 0;
-                while (done < st[i]->whole) {
-                    const uint32_t n = (uint32_t)std::min<uint64_t>(st[i]->whole - done, batch_cap - used);
-                    cur.push_back(Seg{i, done, n});
-                    done += n;
-                    used += n;
-                    if (used == batch_cap) {
-                        batches.push_back(std::move(cur));
-                        cur.clear();
-                        used = 0;
-                    }
-                }
-            }
-            if (!cur.empty()) batches.push_back(std::move(cur));
-        }
-        std::vector<size_t> tails;
-        for (size_t i : ids)
-            if (st[i]->tail) tails.push_back(i);
-        // ---- the workers: hash preparation first (every chain starts at once), then batches, then tails
-        std::atomic<size_t> next_md5{0}, next_batch{0}, next_tail{0};
-        const flacgpu_options g = gpu_options(o, B);
-        const int device = o.device >= 0 ? o.device : flacgpu_current_device();
-        auto work = [&]() {
-            for (size_t k; (k = next_md5.fetch_add(1)) < ids.size();) {
-                Stream &s = *st[ids[k]];
-                const flacenc_job &j = jobs[s.job];
-                const double t0 = now_ms();
-                s.le.resize(j.count * width);
-                pack_le(j.samples, j.count, width, s.le.data());
-                s.lane = Md5Pool::get().attach(&s.md5);
-                s.md5_ticket = Md5Pool::get().push(s.lane, s.le.data(), s.le.size());
-                jobs[s.job].pack_ms += now_ms() - t0;
-            }
-            flacgpu_ctx *ctx = nullptr;
-            CoalesceSlot slot;
-            const CoalesceKey key{g, sh.bps, sh.ch, batch_cap, device};
-            struct View {   // the slot's pinned staging, addressed like the vector it replaces
-                uint8_t *p = nullptr;
-                size_t n = 0;
-                uint8_t *data() const { return p; }
-                size_t size() const { return n; }
-                uint8_t *begin() const { return p; }
-            } out;
-            std::vector<uint64_t> off;
-            auto need_ctx = [&]() -> int {
-                if (ctx) return 0;
-                const int rc = CoalescePool::get().take(key, &slot);
-                if (rc) return rc;
-                ctx = slot.ctx;
-                out.p = slot.out;
-                out.n = slot.cap;
-                off.resize((size_t)batch_cap + 1);
-                return 0;
-            };
-            for (size_t b; (b = next_batch.fetch_add(1)) < batches.size();) {
-                const std::vector<Seg> &segs = batches[b];
-                const double t0 = now_ms();
-                int rc = need_ctx();
-                std::vector<flacgpu_segment> gs(segs.size());
-                for (size_t k = 0; k < segs.size(); k++) {
-                    gs[k].pcm = jobs[st[segs[k].stream]->job].samples + segs[k].first * per;
-                    gs[k].n_frames = segs[k].n;
-                    gs[k].reserved = 0;
-                    gs[k].first_frame_number = segs[k].first;
-                }
-                uint64_t total = 0;
-                if (!rc) rc = flacgpu_encode_segments(ctx, gs.data(), (uint32_t)gs.size(), sh.rate, out.data(), out.size(), off.data(), &total);
-                const double dt = now_ms() - t0;
-                size_t f = 0;
-                for (const Seg &sg : segs) {
-                    Stream &s = *st[sg.stream];
-                    if (rc) {
-                        fail(s.job, FLACENC_ERR_GPU);
-                    } else {
-                        std::lock_guard<std::mutex> l(s.mu);
-                        for (uint32_t k = 0; k < sg.n; k++) s.sizes[sg.first + k] = (uint32_t)(off[f + k + 1] - off[f + k]);
-                        s.chunks.emplace_back(sg.first, std::vector<uint8_t>(out.begin() + off[f], out.begin() + off[f + sg.n]));
-                        jobs[s.job].gpu_ms += dt * sg.n / (double)(off.size() - 1);
-                    }
-                    f += sg.n;
-                }
-            }
-            for (size_t t; (t = next_tail.fetch_add(1)) < tails.size();) {
-                Stream &s = *st[tails[t]];
-                int rc = need_ctx();
-                uint64_t total = 0;
-                if (!rc)
-                    rc = flacgpu_encode_frames(ctx, jobs[s.job].samples + s.whole * per, FLACGPU_LAYOUT_INTERLEAVED, 1, s.tail, s.whole,
-                                               sh.rate, out.data(), out.size(), off.data(), &total);
-                if (rc) {
-                    fail(s.job, FLACENC_ERR_GPU);
-                } else {
-                    std::lock_guard<std::mutex> l(s.mu);
-                    s.sizes[s.whole] = (uint32_t)total;
-                    s.chunks.emplace_back(s.whole, std::vector<uint8_t>(out.begin(), out.begin() + total));
-                }
-            }
-            if (ctx) CoalescePool::get().give(key, slot);
-        };
-        const unsigned workers = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, std::max(batches.size() + tails.size(), ids.size())));
-        WorkerPool::get().run(workers - 1, work);
-        // ---- finish: digest, metadata from the frame sizes, frames in stream order
-        std::atomic<size_t> next_fin{0};
-        auto finish = [&]() {
-            for (size_t k; (k = next_fin.fetch_add(1)) < ids.size();) {
-                Stream &s = *st[ids[k]];
-                flacenc_job &j = jobs[s.job];
-                if (s.lane) {
-                    Md5Pool::get().wait(s.lane, s.md5_ticket);   // the whole chain
-                    j.md5_ms = Md5Pool::get().busy_ms(s.lane);
-                    Md5Pool::get().detach(s.lane);
-                    s.lane = nullptr;
-                }
-                if (j.status) continue;
-                uint8_t digest[16];
-                s.md5.digest(digest);
-                size_t hlen = 0;
-                const uint32_t last_len = s.tail ? s.tail : B;
-                int rc = flacenc_stream_header(&o, sh.rate, sh.bps, sh.ch, s.pcm_frames, digest, s.sizes.size(), s.sizes.data(),
-                                               last_len, j.out, j.out_cap, &hlen);
-                uint64_t body = 0;
-                for (uint32_t z : s.sizes) body += z;
-                if (rc || hlen + body > j.out_cap) {
-                    j.status = rc && rc != FLACENC_ERR_INVALID_ARG ? rc : FLACENC_ERR_IO;
-                    continue;
-                }
-                std::sort(s.chunks.begin(), s.chunks.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-                size_t pos = hlen;
-                for (const auto &c : s.chunks) {
-                    std::memcpy(j.out + pos, c.second.data(), c.second.size());
-                    pos += c.second.size();
-                }
-                j.out_len = pos;
-                j.elapsed_ms = now_ms() - t_begin;
-            }
-        };
-        WorkerPool::get().run((unsigned)std::min<size_t>(nt, ids.size()) - 1, finish);
-    }
-    for (size_t i = 0; i < n_jobs; i++)
-        if (jobs[i].status && !first_error) first_error = jobs[i].status;
-    return first_error;
-}
+// (many SMALL streams -- flacenc_encode_many_coalesced -- live in coalesce.cpp)
 
 // The bytes in front of the first frame (fLaC marker + STREAMINFO + SEEKTABLE + VORBIS_COMMENT +
 // PADDING) exactly as a writer that had produced frames of these sizes would leave them at finalize
@@ -1890,3 +1604,30 @@ const uint8_t *flacenc_stream_writer_data(flacenc_stream_writer *w, size_t *len)
 void flacenc_stream_writer_free(flacenc_stream_writer *w) { delete w; }
 
 }  // extern "C"
+
+// ---- what coalesce.cpp shares with this file (host_internal.h) -----------------------------------------------------------
+namespace flacenc_host {
+double now_ms() { return ::now_ms(); }
+int options_error(const flacenc_options &o) { return ::options_error(o); }
+flacgpu_options gpu_options(const flacenc_options &o, uint32_t block_size) { return ::gpu_options(o, block_size); }
+void pack_le(const int32_t *s, size_t count, unsigned width, uint8_t *d) { ::pack_le(s, count, width, d); }
+int stream_header_len(const flacenc_options &o, uint32_t sample_rate, uint32_t bits_per_sample, uint32_t channels,
+                      uint64_t total_pcm_frames, size_t *len) {
+    flacenc_writer w;
+    w.header_only = true;
+    const int rc = w.init(o, sample_rate, bits_per_sample, channels, true, total_pcm_frames, nullptr);
+    w.finalized = true;   // (nothing to flush: the destructor must not try)
+    if (!rc && len) *len = w.metadata_len;
+    return rc;
+}
+void run_parallel(unsigned helpers, const std::function<void()> &fn) { WorkerPool::get().run(helpers, fn); }
+void release_lane_pool() {
+    std::vector<Lane *> all;
+    {
+        std::lock_guard<std::mutex> lock(lane_pool().mu);
+        for (auto &e : lane_pool().idle) all.push_back(e.second);
+        lane_pool().idle.clear();
+    }
+    for (Lane *l : all) l->destroy();
+}
+}  // namespace flacenc_host

@@ -137,6 +137,16 @@ class GpuAnalyzer:
         if rc:
             raise GpuError(rc, "flacgpu_encode_segments_device")
 
+    def pack_plans(self, pcm, n_frames, last_frame_len, plans, subframes, first_frame_number, sample_rate):
+        """flacgpu_pack_plans: device-side frame assembly of caller-supplied decisions.  Returns (bytes, offsets)."""
+        a = np.ascontiguousarray(pcm, dtype=np.int32)
+        rc = _lib.lib().flacgpu_pack_plans(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), n_frames, last_frame_len, plans,
+                                           subframes, first_frame_number, sample_rate)
+        if rc:
+            raise GpuError(rc, "flacgpu_pack_plans")
+        self.last_frames = n_frames
+        return self.fetch_frames(n_frames)
+
     def pack_device(self, first_frame_number, sample_rate, stream=None):
         """Device-side frame assembly of the last analysed batch (bytes stay in HBM)."""
         rc = _lib.lib().flacgpu_pack_device(self._h, first_frame_number, sample_rate,
@@ -256,6 +266,45 @@ class GpuAnalyzer:
                 L.flacgpu_host_free(hin)
             if hout:
                 L.flacgpu_host_free(hout)
+
+    def encode_segments_packed(self, pcm_le, bytes_per_sample, segments, sample_rate):
+        """flacgpu_encode_segments_packed_async_host in one go: pcm_le = the segments' whole blocks back to back (uint8 array of
+        little-endian samples of bytes_per_sample bytes, or int32 samples viewed as bytes when bytes_per_sample == 4);
+        segments = [(n_frames, first_frame_number), ...].  Pinned buffers both ways.  Returns (bytes, offsets)."""
+        L = _lib.lib()
+        src = np.ascontiguousarray(pcm_le).view(np.uint8).reshape(-1)
+        n_frames = sum(n for n, _ in segments)
+        self.last_frames = n_frames
+        segs = (_lib.Segment * len(segments))()
+        for i, (n, first) in enumerate(segments):
+            segs[i].pcm = None
+            segs[i].n_frames = n
+            segs[i].first_frame_number = first
+        cap = L.flacgpu_packed_cap(self._h)
+        hin = L.flacgpu_host_alloc(src.size + 64)
+        hout = L.flacgpu_host_alloc(cap)
+        try:
+            C.memmove(hin, src.ctypes.data, src.size)
+            rc = L.flacgpu_encode_segments_packed_async_host(self._h, hin, bytes_per_sample, segs, len(segments), sample_rate,
+                                                             hout, cap)
+            if rc:
+                raise GpuError(rc, "flacgpu_encode_segments_packed_async_host")
+            offp = C.POINTER(C.c_uint64)()
+            total = C.c_uint64(0)
+            rc = L.flacgpu_frames_ready(self._h, C.byref(offp), C.byref(total))
+            if rc:
+                raise GpuError(rc, "flacgpu_frames_ready")
+            off = [offp[i] for i in range(n_frames + 1)]
+            rc = L.flacgpu_fetch_frames_async(self._h, hout, cap)
+            if rc:
+                raise GpuError(rc, "flacgpu_fetch_frames_async")
+            rc = L.flacgpu_wait(self._h)
+            if rc:
+                raise GpuError(rc, "flacgpu_wait")
+            return C.string_at(hout, total.value), off
+        finally:
+            L.flacgpu_host_free(hin)
+            L.flacgpu_host_free(hout)
 
     def packed_input_supported(self, bytes_per_sample):
         return bool(_lib.lib().flacgpu_packed_input_supported(self._h, bytes_per_sample))

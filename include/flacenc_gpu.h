@@ -132,7 +132,8 @@ typedef struct {
     /* CUMULATIVE since the context was created (direct stereo input with LPC): candidates whose FIXED partition search and
      * exact bit count were put off behind the LPC half because the LPC size estimate undercut a lower bound of the
      * FIXED size -- fixed_decided: the exact LPC size then lay below the bound, encode.rs:2929-2934 was decided for LPC
-     * without them; fixed_refetched: it did not, the samples were fetched again and counted.  Same bytes either way. */
+     * without them; fixed_refetched: it did not, the samples were fetched again and counted.  Same bytes either way.
+     * Both saturate at 2^32 - 1 (diagnostics of long-lived contexts, not arithmetic). */
     uint32_t fixed_decided;
     uint32_t fixed_refetched;
 } flacgpu_stats;
@@ -300,6 +301,8 @@ int flacgpu_link_probe(int device, size_t bytes, int up_mode, int down_mode, dou
 /* 1 when flacgpu_encode_packed_async takes this sample width for the context's stream shape (a block
  * must be a whole number of 16-byte groups); otherwise widen to int32 and pass bytes_per_sample 4 */
 int flacgpu_packed_input_supported(const flacgpu_ctx *ctx, uint32_t bytes_per_sample);
+/* the same question before a context exists (it depends on the block size, the channel count and the width only) */
+int flacgpu_packed_input_shape_supported(uint32_t block_size, uint32_t channels, uint32_t bytes_per_sample);
 int flacgpu_encode_packed_async(flacgpu_ctx *ctx, const uint8_t *pcm_le, uint32_t bytes_per_sample,
                                 uint32_t n_frames, uint32_t last_frame_len, uint64_t first_frame_number,
                                 uint32_t sample_rate);
@@ -369,6 +372,16 @@ int flacgpu_encode_segments_device(flacgpu_ctx *ctx, const flacgpu_segment *segm
                                    uint32_t sample_rate, void *stream);
 int flacgpu_encode_segments(flacgpu_ctx *ctx, const flacgpu_segment *segments, uint32_t n_segments, uint32_t sample_rate,
                             uint8_t *out, size_t cap, uint64_t *offsets, uint64_t *total);
+/* The asynchronous, stream-width form (r06): what a front end that coalesces many streams needs to keep the link busy.  The
+ * segments' whole blocks lie BACK TO BACK in `pcm_le` (pinned memory; int32 when bytes_per_sample == 4, else the little-endian
+ * ceil(bps / 8)-byte samples of flacgpu_encode_packed_async -- the byte string update_md5 hashes, encode.rs:1292-1318) in
+ * segment order; flacgpu_segment::pcm is ignored.  Upload, analysis and frame assembly are queued and the call returns;
+ * k_frame64 stores the frames straight into `out_host` (pinned, >= flacgpu_packed_cap(ctx) bytes) when every frame takes it.
+ * Results as for flacgpu_encode_packed_async_host: flacgpu_frames_ready (one offset per frame of the batch plus the end),
+ * flacgpu_fetch_frames_async, flacgpu_wait.  `pcm_le` must stay valid until the batch has been waited for. */
+int flacgpu_encode_segments_packed_async_host(flacgpu_ctx *ctx, const uint8_t *pcm_le, uint32_t bytes_per_sample,
+                                              const flacgpu_segment *segments, uint32_t n_segments, uint32_t sample_rate,
+                                              uint8_t *out_host, size_t out_cap);
 
 /* ---- several GPUs ------------------------------------------------------------------------------------
  * A FLAC frame depends on its own samples, the options and its frame number only (encode.rs:2284-2294), so a stream shards

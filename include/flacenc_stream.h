@@ -185,15 +185,18 @@ int flacenc_encode_many(const flacenc_options *opts, flacenc_job *jobs, size_t n
  * one `Encoder` per file in the reference, encode.rs:1882-1980 -- the natural shard; nothing crosses devices).  devices ==
  * NULL with n_devices == FLACENC_ALL_DEVICES: every visible device; NULL / 0: opts->device as flacenc_encode_many.  An
  * ordinal may be listed more than once.  Output is byte-identical to flacenc_encode_many's. */
-/* The same for many SMALL streams: streams of one shape (sample rate, bits per sample, channels) share analysis batches --
- * runs of whole blocks of several streams form one flacgpu_encode_segments call, so that a library of short files runs at
- * the per-sample rate of large batches (a 256-frame batch of 24-bit stereo on its own: 0.3 of it).  A stream's short last
- * block is encoded by a one-frame call, its MD5 runs on the shared engines, its metadata is rebuilt from the frame sizes
- * (flacenc_stream_header).  Output byte-identical to flacenc_encode_many's, stream by stream; every stream is held in
- * memory twice for the duration of the call (its samples and its MD5 byte string).  Meant for streams of a FEW blocks
- * (measured, tools/small_streams_probe.py: 1024 streams of 8 blocks 1.2 against 0.55 Gsamples/s; from ~16 blocks per
- * stream on, flacenc_encode_many's pinned, stream-width uploads win: 256 x 32 blocks 1.1 against 2.3). */
+/* The same with the streams of one shape (sample rate, bits per sample, channels) SHARING analysis batches: runs of whole
+ * blocks of several streams form one batch (every frame with its own stream's frame number), and the batches travel through
+ * a ring of pinned staging buffers -- samples packed to the stream's width on the way in (2 or 3 bytes across PCIe; the packed
+ * bytes are what the MD5 lanes hash), upload of batch i + 1, kernels of batch i and the frames of batch i - 1 in flight
+ * together, frames copied once from the pinned ring to `out`.  A library of short files runs at the per-sample rate of large
+ * batches (a 256-frame batch of 24-bit stereo on its own: 0.3 of it), long streams at the link's.  A stream's short last
+ * block is encoded by a one-frame call, its metadata is rebuilt from the frame sizes (flacenc_stream_header).  Output
+ * byte-identical to flacenc_encode_many's, stream by stream (csrc/host/coalesce.cpp; measured: DESIGN.md section 6). */
 int flacenc_encode_many_coalesced(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads);
+/* Frees what the front ends keep between calls: idle analysis contexts and their pinned staging buffers (the writers' lane
+ * pool, the coalescing ring).  Contexts in use are not touched. */
+void flacenc_release_pools(void);
 #define FLACENC_ALL_DEVICES 0xFFFFFFFFu
 int flacenc_encode_many_devices(const flacenc_options *opts, flacenc_job *jobs, size_t n_jobs, uint32_t threads,
                                 const int *devices, uint32_t n_devices);

@@ -94,6 +94,72 @@ def test_device_segments_in_place_and_gathered(channels, bps):
     an.close()
 
 
+@pytest.mark.parametrize("channels,bps,B", [(2, 24, 4096), (2, 16, 4096), (2, 16, 1152), (1, 24, 4096), (8, 24, 4096), (2, 32, 4096)])
+def test_packed_segments_async_host(channels, bps, B):
+    """flacgpu_encode_segments_packed_async_host (r06): the segments' blocks back to back in ONE pinned buffer at stream width
+    (or int32), frames stored straight into pinned host memory -- the bytes of flacgpu_encode_segments and of the oracle,
+    every frame with its own stream's frame number; an ordinary batch on the same context afterwards numbers its frames
+    from the call again (no stale segment table)."""
+    from test_gpu_packed import le_bytes
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    counts = [4, 1, 6, 2]
+    firsts = [0, 99, 0xFFFFFFF0, 12]
+    streams = _streams(channels, bps, B, counts, 8700 + channels + bps)
+    max_lpc = 12
+    an = GpuAnalyzer(B, 6, max_lpc, True, True, 2, 0.5, bps, channels, max_frames=sum(counts))
+    width = (bps + 7) // 8
+    if not an.packed_input_supported(width):
+        width = 4
+    blob = np.concatenate([le_bytes(s, width) for s in streams])
+    data, off = an.encode_segments_packed(blob, width, list(zip(counts, firsts)), 48000)
+    ref, ref_off = an.encode_segments(list(zip(streams, firsts)), 48000)
+    assert data == ref and list(off) == list(ref_off)
+    f = 0
+    for s, n, first in zip(streams, counts, firsts):
+        want = _expect(s, channels, bps, B, first, 48000, max_lpc)
+        for k in range(n):
+            assert data[off[f]:off[f + 1]] == want[k], f"segment starting at frame {first}: frame {k} differs from the oracle"
+            f += 1
+    own, _ = an.encode_frames(streams[2], counts[2], B, 5, 48000)
+    assert own == b"".join(_expect(streams[2], channels, bps, B, 5, 48000, max_lpc))
+    an.close()
+
+
+def test_plain_batches_after_a_segments_batch_forget_its_tables():
+    """flacgpu_pack_plans and the two-ranges branch of flacgpu_encode_device start a batch without
+    passing the analysis entry that used to clear the segment state; after a segments batch on the same context their frames
+    must carry the call's frame numbers, not the stale table's."""
+    import torch
+
+    from flac_codec_amd.gpu import GpuAnalyzer
+
+    B, ch, bps = 4096, 2, 24
+    n = 256
+    s = synth_fast(8800, ch, bps, B * n)
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=n)
+    an.encode_segments([(s[: B * ch * 100], 5000), (s[B * ch * 100:], 70000)], 48000)
+    want, want_off = an.encode_frames(s, n, B, 3, 48000)
+    # two ranges: eligible from 256 frames on
+    an.set_two_ranges(True)
+    an.encode_segments([(s[: B * ch * 100], 5000), (s[B * ch * 100:], 70000)], 48000)
+    d = torch.from_numpy(s).cuda()
+    an.encode_device(d.data_ptr(), n, B, 3, 48000)
+    got, off = an.fetch_frames()
+    assert got == want and list(off) == list(want_off)
+    res, _ = an.verify_device(48000, 3)
+    assert (res.frames, res.bad_structure, res.bad_crc16, res.frames_pcm_differs) == (n, 0, 0, 0)
+    an.set_two_ranges(False)
+    # pack_plans: the decisions of the plain batch, packed again after another segments batch
+    an.encode_frames(s, n, B, 3, 48000)
+    plans, subs, _ = an.fetch(n, want_residuals=False)
+    an.encode_segments([(s[: B * ch * 100], 5000), (s[B * ch * 100:], 70000)], 48000)
+    got2, off2 = an.pack_plans(s, n, B, plans, subs, 3, 48000)
+    assert got2 == want and list(off2) == list(want_off)
+    an.close()
+
+
 def test_too_many_frames_and_empty_segments_are_refused():
     from flac_codec_amd.gpu import GpuAnalyzer, GpuError
 

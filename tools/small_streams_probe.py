@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Many SMALL streams, host PCM -> .flac: flacenc_encode_many (a writer per stream) against flacenc_encode_many_coalesced
-(shared analysis batches).   python3 tools/small_streams_probe.py [streams] [frames per stream] [threads]"""
+"""Many streams, host PCM -> .flac: flacenc_encode_many (a writer per stream) against flacenc_encode_many_coalesced (shared
+analysis batches through the pinned ring), MD5 included, bytes compared.
+   python3 tools/small_streams_probe.py [--threads T] [--json PATH] [STREAMSxFRAMES ...]     (default: a sweep 1 .. 512 blocks)"""
+import argparse
+import json
 import os
 import statistics
 import sys
@@ -12,24 +15,37 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 from flac_codec_amd.encode import BatchEncoder, Options  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-f = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-th = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+ap = argparse.ArgumentParser()
+ap.add_argument("--threads", type=int, default=32)
+ap.add_argument("--reps", type=int, default=7)
+ap.add_argument("--json", default=None)
+ap.add_argument("shapes", nargs="*", default=["8192x1", "4096x2", "2048x4", "1024x8", "512x16", "256x32", "128x64", "64x128", "64x512"])
+a = ap.parse_args()
 C, B = 2, bench.BLOCK
-pcm = bench.make_pcm(1048, 8192, C, 24)
-step = max(1, (8192 - f) // n)
-streams = [pcm[i * step * B * C: (i * step + f) * B * C] for i in range(n)]
-res = {}
-for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
-    enc = BatchEncoder(Options.best(), threads=th, **kw)
-    got = [bytes(v) for v in enc.encode(streams, 48000, 24, C, copy=False)]
-    ts = []
-    for _ in range(7):
-        t = time.perf_counter()
-        enc.encode(streams, 48000, 24, C, copy=False)
-        ts.append(time.perf_counter() - t)
-    res[name] = got
-    print(f"{name:24s} {n} x {f} frames: median {statistics.median(ts)*1e3:8.2f} ms  best {min(ts)*1e3:8.2f} ms  "
-          f"{n * f * B * C / statistics.median(ts) / 1e6:9.1f} Msamples/s")
-assert res["coalesced"] == res["one_writer_per_stream"]
-print("byte-identical")
+pcm = bench.make_pcm(1048, 8192 + 512, C, 24)
+out = []
+for shape in a.shapes:
+    n, f = (int(v) for v in shape.split("x"))
+    step = max(1, (8192 + 512 - f) // n)
+    streams = [pcm[i * step * B * C: (i * step + f) * B * C] for i in range(n)]
+    rec = {"streams": n, "frames_per_stream": f}
+    res = {}
+    for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
+        enc = BatchEncoder(Options.best(), threads=a.threads, **kw)
+        got = [bytes(v) for v in enc.encode(streams, 48000, 24, C, copy=False)]
+        ts = []
+        for _ in range(a.reps):
+            t = time.perf_counter()
+            enc.encode(streams, 48000, 24, C, copy=False)
+            ts.append(time.perf_counter() - t)
+        res[name] = got
+        rec[name] = {"median_ms": round(statistics.median(ts) * 1e3, 2), "best_ms": round(min(ts) * 1e3, 2),
+                     "Msamples/s": round(n * f * B * C / statistics.median(ts) / 1e6, 1)}
+        print(f"{name:24s} {n:5d} x {f:4d} frames: median {statistics.median(ts)*1e3:8.2f} ms  best {min(ts)*1e3:8.2f} ms  "
+              f"{n * f * B * C / statistics.median(ts) / 1e6:9.1f} Msamples/s", flush=True)
+    rec["byte_identical"] = res["coalesced"] == res["one_writer_per_stream"]
+    print("byte-identical" if rec["byte_identical"] else "BYTES DIFFER", flush=True)
+    out.append(rec)
+if a.json:
+    with open(a.json, "w") as fh:
+        json.dump(out, fh, indent=1)
