@@ -151,6 +151,9 @@ struct flacgpu_ctx {
     bool seg_pending = false;   // the next analyze_impl belongs to a segments call
     bool seg_active = false;    // the batch in hand is made of segments (frame numbers from d_seg_fn)
     bool seg_direct = false;    // ... read in place (Params::inter_tab)
+    bool drained = false;       // nothing of this context is in flight (its last batch was waited for, nothing submitted since):
+                                // the asynchronous entries then skip their hipStreamSynchronize -- with more streams than
+                                // hardware queues a synchronise of an IDLE stream still waits behind the other streams' work
     bool env_no_direct = false;     // FLACGPU_NO_DIRECT as read at creation; copy_input: FLACGPU_TUNE_COPY_INPUT.  knobs.no_direct
     bool copy_input = false;        //   is their OR
     bool ties_checked = true;       // the last analysis has been looked at by resolve_order_ties
@@ -987,6 +990,7 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->last_len = last_len;
     c->last_params = p;
     c->last_stream = st;
+    c->drained = false;
     c->packed_valid = false;
     if (c->timing) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -1235,6 +1239,7 @@ static int pack_impl(flacgpu_ctx *c, uint64_t first_frame_number, uint32_t sampl
     HIP_TRY(hipGetLastError());
     c->packed_valid = true;
     c->last_stream = st;
+    c->drained = false;
     if (c->timing) {
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < 3; i++) {
@@ -1987,8 +1992,10 @@ int flacgpu_encode_segments_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm
         HIP_TRY(hipMalloc((void **)&c->d_seg_ptr, sizeof(int32_t *) * F));
         HIP_TRY(hipHostMalloc((void **)&c->h_seg, sizeof(uint64_t) * 2 * F, hipHostMallocDefault));
     }
-    if (int rc = ctx_sync(c)) return rc;   // (the table's staging copy of the batch before is free; one batch per context at a time)
-    HIP_TRY(hipStreamSynchronize(c->own_stream));
+    if (!c->drained) {   // (the table's staging copy of the batch before must be free; one batch per context at a time)
+        if (int rc = ctx_sync(c)) return rc;
+        HIP_TRY(hipStreamSynchronize(c->own_stream));
+    }
     uint64_t *fn = c->h_seg;
     uint32_t f = 0;
     for (uint32_t i = 0; i < n_segs; i++)
@@ -2007,6 +2014,15 @@ int flacgpu_encode_segments_packed_async_host(flacgpu_ctx *c, const uint8_t *pcm
 static int packed_async_impl(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t bytes_per_sample, uint32_t n_frames, uint32_t last_len,
                              uint64_t first_frame_number, uint32_t sample_rate, uint8_t *out_host, size_t out_cap) {
     hipStream_t st = c->own_stream;
+    // FLACGPU_TRACE_SUBMIT=1: where a submission spends its host time (stderr)
+    static const bool trace = [] {
+        const char *e = getenv("FLACGPU_TRACE_SUBMIT");
+        return e && e[0] && e[0] != '0';
+    }();
+    using clk = std::chrono::steady_clock;
+    const clk::time_point tr0 = clk::now();
+    double tr_up = 0, tr_an = 0, tr_pk = 0;
+    auto since = [&] { return std::chrono::duration<double, std::milli>(clk::now() - tr0).count(); };
     const size_t B = c->opts.block_size, C = c->channels;
     const size_t bytes = ((size_t)(n_frames - 1) * B + last_len) * C * bytes_per_sample;
     // The upward leg.  Default: a copy engine (hipMemcpyAsync).  FLACGPU_UPLOAD_KERNEL=1 (A/B, pinned memory only): the
@@ -2021,15 +2037,18 @@ static int packed_async_impl(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t byt
     } else {
         HIP_TRY(hipMemcpyAsync(c->d_in, pcm_le, bytes, hipMemcpyHostToDevice, st));
     }
+    if (trace) tr_up = since();
     const int arc = analyze_impl(c, c->d_in, FLACGPU_LAYOUT_INTERLEAVED, n_frames, last_len, st,
                                  bytes_per_sample == 4 ? 0 : bytes_per_sample);
     c->packed_src = nullptr;
     if (arc) return arc;
+    if (trace) tr_an = since();
     // the frame sizes leave the device as soon as k_layout has run (second stream), so that the host
     // can size the copy of the bytes while k_frame64 is still assembling them
     c->host_out = (reinterpret_cast<uintptr_t>(out_host) & 3u) ? nullptr : out_host;
     c->host_out_cap = out_cap;
     if (int rc = pack_impl(c, first_frame_number, sample_rate, st, c->ev_layout)) return rc;
+    if (trace) tr_pk = since();
     // frames written straight to the host buffer: they are there when the stream has drained
     if (c->out_in_host)
         if (int rc = record_waitable(c, c->ev_bytes, st)) return rc;
@@ -2051,6 +2070,9 @@ static int packed_async_impl(flacgpu_ctx *c, const uint8_t *pcm_le, uint32_t byt
     if (int rc = record_waitable(c, c->ev_sizes, c->aux_stream)) return rc;
     c->sizes_pending = true;
     c->bytes_pending = false;
+    if (trace)
+        std::fprintf(stderr, "[submit] %u frames, %zu bytes up: upload queued %.3f ms, analysis %.3f, assembly %.3f, all %.3f\n", n_frames, bytes,
+                     tr_up, tr_an - tr_up, tr_pk - tr_an, since());
     return FLACGPU_OK;
 }
 
@@ -2123,9 +2145,13 @@ int flacgpu_wait(flacgpu_ctx *c) {
         if (int rc = wait_waitable(c, c->ev_bytes)) return rc;
         c->bytes_pending = false;
         c->sizes_pending = false;
+        // the frames were stored by the batch's last kernel (out_in_host) or copied by the last command of the context's own
+        // stream, and the sizes' copy on the second stream was waited for by flacgpu_frames_ready: nothing is in flight
+        c->drained = c->last_stream == c->own_stream || c->last_stream == nullptr;
         return FLACGPU_OK;
     }
-    return ctx_sync(c);
+    if (int rc = ctx_sync(c)) return rc;
+    return FLACGPU_OK;
 }
 
 int flacgpu_experiment_mfma_autocorr(flacgpu_ctx *c, float *kernel_ms, uint32_t *compared,

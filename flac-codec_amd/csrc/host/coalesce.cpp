@@ -17,14 +17,29 @@
 //     callers' output buffers (the only host copy of an output byte); a slot is reused once its upload, its frames and the
 //     MD5 runs that read its input are done.  Upload of batch i + 1, kernels of batch i and the frames of batch i - 1 are in
 //     flight together;
+//   * MD5 (one serial chain per stream; a chain's speed is the latency of its 64 dependent steps per 64 bytes: 0.6 GB/s on the
+//     bench host whatever the width) goes two ways.  A stream of up to 32 blocks travels as ONE segment and its chain is run by
+//     a worker: HASH tasks take up to 48 such streams of a batch and advance them in lockstep, three interleaved groups of 16
+//     AVX-512 lanes (md5_mb.cpp: 18 GB/s per thread) -- no engine thread, no queue, no lock.  Longer streams are cut into
+//     segments of a quantum that lets every batch visit every stream, so that all chains advance together, and their runs go
+//     to the shared engine threads in stream order;
+//   * the work is tasks on one queue set -- COPY > RETIRE > PACK > HASH > TAIL > FIN (digest + metadata of a stream whose
+//     parts are through: streams finish while later batches are still in flight) -- drawn by a few workers: the box's CPU
+//     QUOTA (cgroup cpu.max), not its thread count, sizes them, and the first and last batches are quarter-size (the first
+//     upload starts early, little is left behind the last);
 //   * a stream's short last block is one synchronous one-frame call on a small context of its own kind; everything in front
 //     of the first frame is rebuilt from the frame sizes (flacenc_stream_header) -- the bytes Encoder::new / encode /
 //     finalize_inner leave (encode.rs:1882-2110), stream by stream.
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <sys/resource.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -123,6 +138,8 @@ struct RingPool {
     }
 };
 
+constexpr uint32_t kSolo = 32;   // blocks: streams up to this long are "solo"
+
 struct Stream {
     size_t job = 0;
     uint64_t pcm_frames = 0, whole = 0;   // samples per channel, whole blocks
@@ -135,6 +152,10 @@ struct Stream {
     std::vector<uint8_t> le;              // the whole byte string, only when the upload cannot take the stream's width
     Md5 md5;
     Md5Lane *lane = nullptr;
+    bool attach_tried = false;            // the lane is attached by the first run (under mu)
+    bool solo = false;                    // a stream of a few blocks: ONE segment, hashed by the worker that packs it
+    std::atomic<int> parts_left{0};       // the run of whole blocks, the short last block: the stream is finished when both are through
+    size_t last_batch = 0;                // batch of its last whole-block segment
     // MD5 runs are pushed in stream order whatever the order the packers finish in
     std::mutex mu;
     uint64_t next_md5_frame = 0;
@@ -160,7 +181,9 @@ struct Batch {
     std::vector<Seg> segs;
     uint32_t frames = 0;
     int slot = -1;
-    std::atomic<uint32_t> pack_left{0}, copy_left{0};
+    std::atomic<uint32_t> pack_left{0}, copy_left{0}, hash_left{0};
+    std::atomic<uint32_t> release_left{2};   // the frames copied out, the solo chains hashed: the second one through frees the slot
+    std::vector<uint32_t> solo_idx;          // segments hashed by HASH tasks (filled at submission)
     bool submitted = false, failed = false;
     Batch() = default;
     Batch(Batch &&o) noexcept : segs(std::move(o.segs)), frames(o.frames), slot(o.slot), submitted(o.submitted), failed(o.failed) {}
@@ -171,11 +194,58 @@ struct CopyJob {
     size_t n;
 };
 struct Task {
-    enum Kind { NONE, PACK, COPY, RETIRE, TAIL } kind = NONE;
-    size_t batch = 0, i0 = 0, i1 = 0;   // PACK: segments [i0, i1) of the batch; COPY: copy jobs [i0, i1); TAIL: stream i0
+    enum Kind { NONE, PACK, COPY, RETIRE, TAIL, FIN, HASH } kind = NONE;
+    size_t batch = 0, i0 = 0, i1 = 0;   // PACK: segments [i0, i1) of the batch; COPY: copy jobs [i0, i1); TAIL: stream i0; FIN: fin_list[i0, i1); HASH: solo_idx[i0, i1)
 };
 
 }  // namespace
+
+// CPUs this process may really use: the cgroup's CPU quota (a container with 16 CPUs' worth of time on a 256-thread host
+// is throttled for the rest of the period once its threads have burnt the quota -- more runnable threads than that only add
+// stalls), else the hardware threads
+namespace flacenc_host {
+unsigned usable_cpus() {
+    static const unsigned n = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+            char q[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+                const long quota = std::atol(q);
+                if (quota > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long>(1, (quota + period / 2) / period));
+            }
+            std::fclose(f);
+        } else {
+            long quota = -1, period = 0;
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+                if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+                std::fclose(g);
+            }
+            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(g, "%ld", &period) != 1) period = 0;
+                std::fclose(g);
+            }
+            if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long>(1, (quota + period / 2) / period));
+        }
+        return hw;
+    }();
+    return n;
+}
+}  // namespace flacenc_host
+static double cpu_ms() {   // user + system time of the whole process
+    rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return (r.ru_utime.tv_sec + r.ru_stime.tv_sec) * 1e3 + (r.ru_utime.tv_usec + r.ru_stime.tv_usec) * 1e-3;
+}
+
+// FLACENC_TRACE=1: the phases of a call on stderr (milliseconds since its start)
+static bool trace_on() {
+    static const bool on = [] {
+        const char *e = std::getenv("FLACENC_TRACE");
+        return e && e[0] && e[0] != '0';
+    }();
+    return on;
+}
 
 extern "C" {
 
@@ -196,6 +266,9 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
     std::map<Shape, std::vector<size_t>> groups;
     std::vector<std::unique_ptr<Stream>> st(n_jobs);
     const double t_begin = now_ms();
+    const double cpu_begin = trace_on() ? cpu_ms() : 0.0;
+    // (streams of one length share their header's size: the check constructs a header-only writer)
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, uint64_t>, std::pair<int, size_t>> header_memo;
     for (size_t i = 0; i < n_jobs; i++) {
         flacenc_job &j = jobs[i];
         j.out_len = 0;
@@ -207,9 +280,19 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             continue;
         }
         size_t hlen = 0;
-        if (int rc = stream_header_len(o, j.sample_rate, j.bits_per_sample, j.channels, j.count / j.channels, &hlen)) {
-            j.status = rc;
-            continue;
+        {
+            const auto mk = std::make_tuple(j.sample_rate, j.bits_per_sample, j.channels, (uint64_t)(j.count / j.channels));
+            auto it = header_memo.find(mk);
+            if (it == header_memo.end()) {
+                size_t l = 0;
+                const int rc = stream_header_len(o, j.sample_rate, j.bits_per_sample, j.channels, j.count / j.channels, &l);
+                it = header_memo.emplace(mk, std::make_pair(rc, l)).first;
+            }
+            if (it->second.first) {
+                j.status = it->second.first;
+                continue;
+            }
+            hlen = it->second.second;
         }
         st[i].reset(new Stream());
         Stream &s = *st[i];
@@ -221,8 +304,10 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
         s.sizes.assign(s.whole + (s.tail ? 1 : 0), 0);
         groups[Shape{j.sample_rate, j.bits_per_sample, j.channels}].push_back(i);
     }
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = std::max(1u, std::min<unsigned>(threads ? threads : std::min(hw / 2 ? hw / 2 : 1u, 12u), 64u));
+    if (trace_on()) std::fprintf(stderr, "[coalesce] %zu streams checked at %.2f ms\n", n_jobs, now_ms() - t_begin);
+    // workers: packing, copying and one waiting for the GPU -- a few; the MD5 engines and the runtime's own threads need CPUs too
+    const unsigned cpus = usable_cpus();
+    const unsigned nt = std::max(1u, std::min<unsigned>(threads ? threads : std::max(2u, std::min(cpus > 6 ? cpus - 6 : 2u, 10u)), 64u));
     std::mutex err_mu;
     auto fail = [&](size_t job, int rc) {
         std::lock_guard<std::mutex> l(err_mu);
@@ -253,22 +338,53 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
         batch_cap = (uint32_t)std::min<uint64_t>(batch_cap, std::max<uint64_t>(total_whole, 1));
         std::vector<Batch> batches;
         {
+            // batch sizes: the first and the last ones smaller (a quarter, a half of the cap) -- the first upload starts after a
+            // quarter of a batch has been packed, and behind the last upload only a quarter of a batch is left to analyse,
+            // assemble and copy
+            std::vector<uint32_t> plan;
+            {
+                uint64_t left = total_whole;
+                std::vector<uint32_t> head, tailv;
+                for (uint32_t z : {batch_cap / 4, batch_cap / 2}) {
+                    if (z >= 64 && left >= 4ull * z) {
+                        head.push_back(z);
+                        tailv.push_back(z);
+                        left -= 2ull * z;
+                    }
+                }
+                plan = head;
+                while (left) {
+                    const uint32_t z = (uint32_t)std::min<uint64_t>(left, batch_cap);
+                    plan.push_back(z);
+                    left -= z;
+                }
+                for (size_t i = tailv.size(); i-- > 0;) plan.push_back(tailv[i]);
+            }
             std::vector<uint64_t> done(n_jobs, 0);
             std::deque<size_t> active;
-            for (size_t i : ids)
+            for (size_t i : ids) {
+                // streams of up to kSolo blocks travel as ONE segment and are hashed by the worker that packs them (below)
+                st[i]->solo = st[i]->whole && st[i]->whole <= kSolo;
+                st[i]->attach_tried = st[i]->whole <= kSolo;   // (no engine lane: their short last block is hashed where it is packed)
                 if (st[i]->whole) active.push_back(i);
-            while (!active.empty()) {
+            }
+            for (size_t pi = 0; !active.empty(); pi++) {
+                const uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
                 Batch b;
-                // a quantum that lets a batch visit every active stream, but no less than 8 blocks (a stream of a few blocks goes whole)
-                const uint32_t q = std::max<uint32_t>(8u, (uint32_t)((batch_cap + active.size() - 1) / active.size()));
-                while (b.frames < batch_cap && !active.empty()) {
+                // a quantum that lets a batch visit every active stream, but no less than kSolo blocks
+                const uint32_t q = std::max<uint32_t>(kSolo, (uint32_t)((cap + active.size() - 1) / active.size()));
+                while (b.frames < cap && !active.empty()) {
                     const size_t i = active.front();
+                    const uint32_t want = (uint32_t)std::min<uint64_t>(q, st[i]->whole - done[i]);
+                    if (want > cap - b.frames && st[i]->solo && b.frames) break;   // a solo stream is never cut: it opens the next batch
                     active.pop_front();
-                    const uint32_t n = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(q, st[i]->whole - done[i]), batch_cap - b.frames);
+                    const uint32_t n = std::min<uint32_t>(want, cap - b.frames);
                     b.segs.emplace_back(i, done[i], n, b.frames);
                     b.frames += n;
                     done[i] += n;
-                    if (done[i] < st[i]->whole) active.push_back(i);
+                    if (done[i] == st[i]->whole) st[i]->last_batch = batches.size();
+                    else if (n < want) active.push_front(i);   // (cut by the batch's end: it goes on first in the next one)
+                    else active.push_back(i);
                 }
                 batches.push_back(std::move(b));
             }
@@ -281,7 +397,7 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
         const RingKey key{g, sh.bps, sh.ch, batch_cap, device};
         const RingKey tail_key{g, sh.bps, sh.ch, 1u, device};
         const size_t in_bytes = (size_t)batch_cap * per * up_width;
-        const unsigned depth = (unsigned)std::min<size_t>(std::max<size_t>(batches.size(), 1), o.pipeline_depth ? std::min<uint32_t>(o.pipeline_depth, 8u) : 4u);
+        const unsigned depth = (unsigned)std::min<size_t>(std::max<size_t>(batches.size(), 1), o.pipeline_depth ? std::min<uint32_t>(o.pipeline_depth, 8u) : 6u);
         std::vector<RingSlot> slots;
         int ring_rc = 0;
         for (unsigned d = 0; d < depth && !batches.empty(); d++) {
@@ -298,10 +414,16 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             continue;
         }
 
+        if (trace_on())
+            std::fprintf(stderr, "[coalesce] %zu batches of <= %u frames, %u slots, width %u -> %u, ring ready at %.2f ms\n", batches.size(),
+                         batch_cap, (unsigned)slots.size(), width, up_width, now_ms() - t_begin);
         // ---- scheduler state
         std::mutex mu;
         std::condition_variable cv;
-        std::deque<Task> copyq, packq, tailq;
+        std::deque<Task> copyq, packq, hashq, tailq, finq;
+        std::function<void(size_t)> release_slot_fn;   // (release_slot, defined below the tasks that end with it)
+        std::vector<size_t> fin_list;     // streams ready to be finished, in the order they became ready (mu)
+        size_t fin_queued = 0, fin_left = ids.size();
         std::vector<int> free_slots;
         for (int d = (int)slots.size() - 1; d >= 0; d--) free_slots.push_back(d);
         size_t next_assign = 0, retire_next = 0, batches_done = 0, tails_left = tails.size();
@@ -313,6 +435,20 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             k.i0 = t;
             tailq.push_back(k);
         }
+        for (size_t i : ids) st[i]->parts_left.store((st[i]->whole ? 1 : 0) + (st[i]->tail ? 1 : 0));
+        fin_list.reserve(ids.size());
+        // (mu held) a part of the stream is through; the last one makes it ready to be finished -- tasks of up to 32 streams
+        auto part_done = [&](size_t id, bool flush) {
+            if (id != (size_t)-1 && st[id]->parts_left.fetch_sub(1) == 1) fin_list.push_back(id);
+            while (fin_list.size() - fin_queued >= 32 || (flush && fin_list.size() > fin_queued)) {
+                Task k;
+                k.kind = Task::FIN;
+                k.i0 = fin_queued;
+                k.i1 = std::min(fin_list.size(), fin_queued + 32);
+                fin_queued = k.i1;
+                finq.push_back(k);
+            }
+        };
         // (mu held) hand the free slots to the next batches and queue their packing, a few segments per task
         auto assign = [&]() {
             while (!free_slots.empty() && next_assign < batches.size()) {
@@ -323,10 +459,13 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 size_t i0 = 0;
                 uint32_t ntasks = 0;
                 std::vector<Task> ts;
-                while (i0 < ns) {   // ~128 frames of packing per task
+                // packing tasks: a batch is cut into about as many as there are workers (memory-bound work: no gain from size), 32 ..
+                // 256 frames each
+                const uint32_t fr_target = std::min(256u, std::max(32u, (b.frames + nt - 1) / nt));
+                while (i0 < ns) {
                     size_t i1 = i0;
                     uint32_t fr = 0;
-                    while (i1 < ns && fr < 128) fr += b.segs[i1++].n;
+                    while (i1 < ns && fr < fr_target) fr += b.segs[i1++].n;
                     Task k;
                     k.kind = Task::PACK;
                     k.batch = next_assign;
@@ -344,6 +483,10 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
         // a stream's MD5 runs in stream order: a segment packed ahead of its predecessors waits in the stream's list
         auto md5_push = [&](Stream &s, uint64_t first, uint32_t frames, const uint8_t *p, size_t n, std::atomic<uint64_t> *ticket) {
             std::lock_guard<std::mutex> l(s.mu);
+            if (!s.attach_tried) {   // the chain's lane on the shared engines, with its first run
+                s.attach_tried = true;
+                s.lane = Md5Pool::get().attach(&s.md5);
+            }
             if (!s.lane) {   // (no engine lane: hash here, in order all the same)
                 s.pending.emplace(first, Stream::Pending{p, n, frames, ticket});
                 for (auto it = s.pending.begin(); it != s.pending.end() && it->first == s.next_md5_frame; it = s.pending.erase(it)) {
@@ -360,6 +503,9 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 if (it->second.ticket) it->second.ticket->store(s.last_ticket, std::memory_order_release);
             }
         };
+        const bool no_md5 = trace_on() && std::getenv("FLACENC_TIMING_NO_MD5");
+        // PACK: the callers' samples of a few segments into the slot's input at the upload's width; the runs of the longer
+        // streams go to the MD5 engines as they are packed, the last packer of the batch submits it and queues its HASH tasks
         auto run_pack = [&](const Task &k) {
             Batch &b = batches[k.batch];
             RingSlot &slot = slots[(size_t)b.slot];
@@ -371,16 +517,18 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 const int32_t *src = j.samples + sg.first * per;
                 const size_t count = (size_t)sg.n * per;
                 uint8_t *dst = slot.in + (size_t)sg.boff * per * up_width;
+                const uint8_t *le = dst;
                 if (up_width == width) {
                     pack_le(src, count, width, dst);
-                    md5_push(s, sg.first, sg.n, dst, count * width, &sg.ticket);
                 } else {   // the upload takes int32 only: the MD5 bytes are packed beside it, into the stream's own string
                     std::memcpy(dst, src, count * 4);
-                    uint8_t *le = s.le.data() + sg.first * per * width;
-                    pack_le(src, count, width, le);
-                    md5_push(s, sg.first, sg.n, le, count * width, nullptr);
-                    sg.ticket.store(~0ull, std::memory_order_release);   // (the slot's input is not what the MD5 reads)
+                    uint8_t *l2 = s.le.data() + sg.first * per * width;
+                    pack_le(src, count, width, l2);
+                    le = l2;
                 }
+                if (no_md5) sg.ticket.store(~0ull, std::memory_order_release);   // (FLACENC_TIMING_NO_MD5: wrong digests, timing only)
+                else if (!s.solo) md5_push(s, sg.first, sg.n, le, count * width, up_width == width ? &sg.ticket : nullptr);
+                if (!no_md5 && !s.solo && up_width != width) sg.ticket.store(~0ull, std::memory_order_release);   // (the slot's input is not what the MD5 reads)
             }
             const double dt = now_ms() - t0;
             for (size_t i = k.i0; i < k.i1; i++) {
@@ -396,15 +544,109 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 gs[i].n_frames = b.segs[i].n;
                 gs[i].reserved = 0;
                 gs[i].first_frame_number = b.segs[i].first;
+                if (!no_md5 && st[b.segs[i].stream]->solo) b.solo_idx.push_back((uint32_t)i);
             }
             const int rc = flacgpu_encode_segments_packed_async_host(slot.ctx, slot.in, up_width, gs.data(), (uint32_t)gs.size(), sh.rate,
                                                                      slot.out, slot.out_cap);
+            if (trace_on()) std::fprintf(stderr, "[coalesce] batch %zu (%u frames, %zu segments) submitted at %.2f ms\n", k.batch, b.frames, b.segs.size(), now_ms() - t_begin);
+            // HASH tasks: the batch's solo streams, up to 48 chains each
+            std::vector<Task> hs;
+            for (size_t j0 = 0; j0 < b.solo_idx.size(); j0 += 48) {
+                Task h;
+                h.kind = Task::HASH;
+                h.batch = k.batch;
+                h.i0 = j0;
+                h.i1 = std::min(b.solo_idx.size(), j0 + 48);
+                hs.push_back(h);
+            }
+            b.hash_left.store((uint32_t)hs.size());
+            bool release_now = false;
             {
                 std::lock_guard<std::mutex> l(mu);
                 b.failed = rc != 0;
                 b.submitted = true;
+                for (auto &h : hs) hashq.push_back(h);
             }
+            if (hs.empty()) release_now = b.release_left.fetch_sub(1) == 1;
             cv.notify_all();
+            if (release_now) release_slot_fn(k.batch);
+        };
+        // HASH: the chains of up to 48 solo streams of a batch in lockstep (md5_blocks_groups) over the bytes packed into the
+        // slot -- each chain is ONE run from the state RFC 1321 starts with: no engine thread, no queue, no lock.  A chain's
+        // speed is bound by the latency of its 64 dependent steps per block, so the lanes count, not the bytes: the tasks are
+        // as wide as the registers allow and take about 40 us per block of the longest stream.  Lanes of different lengths
+        // drop out as they end.
+        auto run_hash = [&](const Task &k) {
+            Batch &b = batches[k.batch];
+            RingSlot &slot = slots[(size_t)b.slot];
+            const size_t frame_bytes = per * width;
+            struct Lane {
+                Seg *sg;
+                const uint8_t *p;
+                uint32_t done;
+            };
+            Lane lanes[48];
+            Lane *live[48];
+            size_t nl = 0;
+            for (size_t j = k.i0; j < k.i1; j++) {
+                Seg &sg = b.segs[b.solo_idx[j]];
+                const uint8_t *p = up_width == width ? slot.in + (size_t)sg.boff * per * up_width
+                                                     : st[sg.stream]->le.data() + sg.first * per * width;
+                lanes[nl] = Lane{&sg, p, 0};
+                live[nl] = &lanes[nl];
+                nl++;
+            }
+            alignas(64) uint32_t stt[3][4][16];
+            while (nl) {
+                // as many blocks at a time as every live lane still has
+                uint32_t common = ~0u;
+                for (size_t i = 0; i < nl; i++) common = std::min(common, live[i]->sg->n - live[i]->done);
+                const size_t bytes = (size_t)common * frame_bytes;
+                if (nl >= 2 && bytes % 64 == 0) {
+                    const int groups = (int)((nl + 15) / 16);
+                    const uint8_t *ptr[3][16];
+                    uint32_t mask[3] = {0, 0, 0};
+                    for (size_t i = 0; i < nl; i++) {
+                        const int g = (int)(i % groups), l = (int)(i / groups);
+                        uint32_t w4[4];
+                        st[live[i]->sg->stream]->md5.get_state(w4);
+                        for (int w = 0; w < 4; w++) stt[g][w][l] = w4[w];
+                        ptr[g][l] = live[i]->p + (size_t)live[i]->done * frame_bytes;
+                        mask[g] |= 1u << l;
+                    }
+                    md5_blocks_groups(stt, ptr, bytes / 64, mask, groups);
+                    for (size_t i = 0; i < nl; i++) {
+                        const int g = (int)(i % groups), l = (int)(i / groups);
+                        const uint32_t w4[4] = {stt[g][0][l], stt[g][1][l], stt[g][2][l], stt[g][3][l]};
+                        Md5 &m = st[live[i]->sg->stream]->md5;
+                        m.set_state(w4);
+                        m.add_blocks(bytes / 64);
+                    }
+                } else {   // a lone chain, or runs that are not whole MD5 blocks: the scalar code
+                    for (size_t i = 0; i < nl; i++) st[live[i]->sg->stream]->md5.update(live[i]->p + (size_t)live[i]->done * frame_bytes, bytes);
+                }
+                size_t w = 0;
+                for (size_t i = 0; i < nl; i++) {
+                    Lane *l = live[i];
+                    l->done += common;
+                    if (l->done < l->sg->n) {
+                        live[w++] = l;
+                        continue;
+                    }
+                    Stream &s = *st[l->sg->stream];
+                    {   // the stream's short last block (if its task ran first) follows in order
+                        std::lock_guard<std::mutex> lk(s.mu);
+                        s.next_md5_frame += l->sg->n;
+                        for (auto it = s.pending.begin(); it != s.pending.end() && it->first == s.next_md5_frame; it = s.pending.erase(it)) {
+                            s.md5.update(it->second.p, it->second.n);
+                            s.next_md5_frame += it->second.frames;
+                        }
+                    }
+                    l->sg->ticket.store(~0ull, std::memory_order_release);
+                }
+                nl = w;
+            }
+            if (b.hash_left.fetch_sub(1) == 1 && b.release_left.fetch_sub(1) == 1) release_slot_fn(k.batch);
         };
         // (any thread) the batch's frames are in their places: its slot is free once the MD5 runs that read its input are done
         auto release_slot = [&](size_t bi) {
@@ -415,14 +657,20 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 Stream &s = *st[sg.stream];
                 if (t != ~0ull && s.lane) Md5Pool::get().wait(s.lane, t);
             }
+            if (trace_on()) std::fprintf(stderr, "[coalesce] batch %zu's slot free at %.2f ms\n", bi, now_ms() - t_begin);
             {
                 std::lock_guard<std::mutex> l(mu);
                 free_slots.push_back(b.slot);
                 batches_done++;
                 assign();
+                // the streams whose last whole block was in this batch: frames in place, MD5 runs of the whole blocks done
+                for (Seg &sg : b.segs)
+                    if (st[sg.stream]->last_batch == bi && sg.first + sg.n == st[sg.stream]->whole) part_done(sg.stream, false);
+                part_done((size_t)-1, batches_done == batches.size());
             }
             cv.notify_all();
         };
+        release_slot_fn = release_slot;
         auto run_retire = [&](size_t bi) {
             Batch &b = batches[bi];
             RingSlot &slot = slots[(size_t)b.slot];
@@ -434,6 +682,7 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             if (!rc) rc = flacgpu_wait(slot.ctx);
             else if (!b.failed) (void)flacgpu_wait(slot.ctx);
             const double dt = now_ms() - t0;
+            if (trace_on()) std::fprintf(stderr, "[coalesce] batch %zu retired at %.2f ms (waited %.2f)\n", bi, now_ms() - t_begin, dt);
             std::vector<CopyJob> &cj = copy_jobs[bi];
             uint32_t f = 0;
             for (Seg &sg : b.segs) {
@@ -476,12 +725,12 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 retire_next++;
             }
             cv.notify_all();
-            if (ts.empty()) release_slot(bi);
+            if (ts.empty() && b.release_left.fetch_sub(1) == 1) release_slot(bi);
         };
         auto run_copy = [&](const Task &k) {
             const std::vector<CopyJob> &cj = copy_jobs[k.batch];
             for (size_t i = k.i0; i < k.i1; i++) std::memcpy(cj[i].dst, cj[i].src, cj[i].n);
-            if (batches[k.batch].copy_left.fetch_sub(1) == 1) release_slot(k.batch);
+            if (batches[k.batch].copy_left.fetch_sub(1) == 1 && batches[k.batch].release_left.fetch_sub(1) == 1) release_slot(k.batch);
         };
         // a stream's short last block: one frame, synchronously, on a one-frame context (one per worker that meets a tail)
         auto run_tail = [&](size_t id, RingSlot &tslot, bool &have) {
@@ -510,21 +759,55 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             {
                 std::lock_guard<std::mutex> l(mu);
                 tails_left--;
+                part_done(id, tails_left == 0);
             }
             cv.notify_all();
         };
 
-        // ---- MD5 lanes first (every chain is attached before its first run arrives), then the workers
-        for (size_t i : ids) {
-            Stream &s = *st[i];
-            s.lane = Md5Pool::get().attach(&s.md5);
-            if (up_width != width) s.le.resize((size_t)s.whole * per * width);
-        }
+        // ---- a stream whose parts are through: digest, metadata from the frame sizes, the tail frame behind the whole blocks' frames
+        auto finish_stream = [&](size_t id) {
+            Stream &s = *st[id];
+            flacenc_job &j = jobs[s.job];
+            Md5Lane *lane;
+            uint64_t ticket;
+            {
+                std::lock_guard<std::mutex> l(s.mu);
+                lane = s.lane;
+                ticket = s.last_ticket;
+                s.lane = nullptr;
+            }
+            if (lane) {
+                Md5Pool::get().wait(lane, ticket);   // the whole chain
+                j.md5_ms = Md5Pool::get().busy_ms(lane);
+                Md5Pool::get().detach(lane);
+            }
+            if (has_failed(s.job)) return;
+            uint8_t digest[16];
+            s.md5.digest(digest);
+            size_t hlen = 0;
+            const uint32_t last_len = s.tail ? s.tail : B;
+            int rc = flacenc_stream_header(&o, sh.rate, sh.bps, sh.ch, s.pcm_frames, digest, s.sizes.size(), s.sizes.data(), last_len, j.out,
+                                           j.out_cap, &hlen);
+            if (!rc && hlen != s.hlen) rc = FLACENC_ERR_IO;   // (cannot happen: the header's size is fixed at `new`)
+            if (rc || s.hlen + s.pos + s.tail_bytes.size() > j.out_cap) {
+                fail(s.job, rc && rc != FLACENC_ERR_INVALID_ARG ? rc : FLACENC_ERR_IO);
+                return;
+            }
+            if (!s.tail_bytes.empty()) std::memcpy(j.out + s.hlen + s.pos, s.tail_bytes.data(), s.tail_bytes.size());
+            j.out_len = s.hlen + s.pos + s.tail_bytes.size();
+            j.elapsed_ms = now_ms() - t_begin;
+        };
+        // ---- the workers (a stream's MD5 lane is attached with its first run)
+        if (up_width != width)
+            for (size_t i : ids) st[i]->le.resize((size_t)st[i]->whole * per * width);
         {
             std::lock_guard<std::mutex> l(mu);
             assign();
         }
+        if (trace_on()) std::fprintf(stderr, "[coalesce] workers start at %.2f ms\n", now_ms() - t_begin);
+        std::atomic<unsigned> next_wid{0};
         auto work = [&]() {
+            const unsigned wid = next_wid.fetch_add(1);
             RingSlot tslot;
             bool have_tslot = false;
             for (;;) {
@@ -537,15 +820,20 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                             copyq.pop_front();
                             break;
                         }
+                        if (!retiring && retire_next < batches.size() && batches[retire_next].submitted) {
+                            retiring = true;
+                            k.kind = Task::RETIRE;
+                            k.batch = retire_next;
+                            break;
+                        }
                         if (!packq.empty()) {
                             k = packq.front();
                             packq.pop_front();
                             break;
                         }
-                        if (!retiring && retire_next < batches.size() && batches[retire_next].submitted) {
-                            retiring = true;
-                            k.kind = Task::RETIRE;
-                            k.batch = retire_next;
+                        if (!hashq.empty()) {
+                            k = hashq.front();
+                            hashq.pop_front();
                             break;
                         }
                         if (!tailq.empty()) {
@@ -553,7 +841,12 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                             tailq.pop_front();
                             break;
                         }
-                        if (batches_done == batches.size() && tails_left == 0) {
+                        if (!finq.empty()) {
+                            k = finq.front();
+                            finq.pop_front();
+                            break;
+                        }
+                        if (fin_left == 0) {
                             k.kind = Task::NONE;
                             break;
                         }
@@ -561,48 +854,45 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                     }
                 }
                 if (k.kind == Task::NONE) break;
+                const double tt0 = trace_on() ? now_ms() : 0.0;
                 if (k.kind == Task::PACK) run_pack(k);
                 else if (k.kind == Task::COPY) run_copy(k);
                 else if (k.kind == Task::RETIRE) run_retire(k.batch);
-                else run_tail(k.i0, tslot, have_tslot);
+                else if (k.kind == Task::HASH) run_hash(k);
+                else if (k.kind == Task::TAIL) run_tail(k.i0, tslot, have_tslot);
+                else {
+                    for (size_t i = k.i0; i < k.i1; i++) {
+                        size_t id;
+                        {
+                            std::lock_guard<std::mutex> l(mu);   // (fin_list grows under mu)
+                            id = fin_list[i];
+                        }
+                        finish_stream(id);
+                    }
+                    bool last;
+                    {
+                        std::lock_guard<std::mutex> l(mu);
+                        fin_left -= k.i1 - k.i0;
+                        last = fin_left == 0;
+                    }
+                    if (last) cv.notify_all();
+                }
+                if (trace_on() && std::getenv("FLACENC_TRACE_TASKS"))
+                    std::fprintf(stderr, "[task] w%u %s b%zu [%zu,%zu) %.3f -> %.3f\n", wid, k.kind == Task::PACK ? "pack" : k.kind == Task::COPY ? "copy" : k.kind == Task::RETIRE ? "retire" : k.kind == Task::TAIL ? "tail" : k.kind == Task::HASH ? "hash" : "fin",
+                                 k.batch, k.i0, k.i1, tt0 - t_begin, now_ms() - t_begin);
             }
             if (have_tslot) RingPool::get().give(tail_key, tslot);
         };
         const unsigned workers = (unsigned)std::min<size_t>(nt, std::max<size_t>(1, total_whole / 64 + tails.size() + 1));
         run_parallel(workers - 1, work);
+        if (trace_on()) std::fprintf(stderr, "[coalesce] %u workers done at %.2f ms\n", workers, now_ms() - t_begin);
         for (auto &s : slots) RingPool::get().give(key, s);
 
-        // ---- finish: digest, metadata from the frame sizes, the tail frame behind the whole blocks' frames
-        std::atomic<size_t> next_fin{0};
-        auto finish = [&]() {
-            for (size_t k; (k = next_fin.fetch_add(1)) < ids.size();) {
-                Stream &s = *st[ids[k]];
-                flacenc_job &j = jobs[s.job];
-                if (s.lane) {
-                    Md5Pool::get().wait(s.lane, s.last_ticket);   // the whole chain
-                    j.md5_ms = Md5Pool::get().busy_ms(s.lane);
-                    Md5Pool::get().detach(s.lane);
-                    s.lane = nullptr;
-                }
-                if (j.status) continue;
-                uint8_t digest[16];
-                s.md5.digest(digest);
-                size_t hlen = 0;
-                const uint32_t last_len = s.tail ? s.tail : B;
-                int rc = flacenc_stream_header(&o, sh.rate, sh.bps, sh.ch, s.pcm_frames, digest, s.sizes.size(), s.sizes.data(), last_len,
-                                               j.out, j.out_cap, &hlen);
-                if (!rc && hlen != s.hlen) rc = FLACENC_ERR_IO;   // (cannot happen: the header's size is fixed at `new`)
-                if (rc || s.hlen + s.pos + s.tail_bytes.size() > j.out_cap) {
-                    j.status = rc && rc != FLACENC_ERR_INVALID_ARG ? rc : FLACENC_ERR_IO;
-                    continue;
-                }
-                if (!s.tail_bytes.empty()) std::memcpy(j.out + s.hlen + s.pos, s.tail_bytes.data(), s.tail_bytes.size());
-                j.out_len = s.hlen + s.pos + s.tail_bytes.size();
-                j.elapsed_ms = now_ms() - t_begin;
-            }
-        };
-        run_parallel((unsigned)std::min<size_t>(nt, std::max<size_t>(1, ids.size() / 16)) - 1, finish);
+        if (trace_on()) std::fprintf(stderr, "[coalesce] finished at %.2f ms\n", now_ms() - t_begin);
     }
+    if (trace_on())
+        std::fprintf(stderr, "[coalesce] call done at %.2f ms, %.1f CPU-ms of the process (%u usable CPUs, %u workers)\n", now_ms() - t_begin,
+                     cpu_ms() - cpu_begin, cpus, nt);
     int first_error = 0;
     for (size_t i = 0; i < n_jobs; i++)
         if (jobs[i].status && !first_error) first_error = jobs[i].status;

@@ -20,6 +20,8 @@ int stream_header_len(const flacenc_options &o, uint32_t sample_rate, uint32_t b
                       uint64_t total_pcm_frames, size_t *len);
 // `helpers` parked threads of the process-wide pool run fn() side by side with the caller; returns when all are done
 void run_parallel(unsigned helpers, const std::function<void()> &fn);
+// CPUs this process may really use: the cgroup's CPU quota when there is one (coalesce.cpp), else the hardware threads
+unsigned usable_cpus();
 // idle analysis lanes of the per-stream writers (flacenc_release_pools)
 void release_lane_pool();
 

