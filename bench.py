@@ -273,7 +273,9 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     # (64 batches per timed loop: with 16 the loop's ramp -- the first uploads with nothing to overlap -- and its drain were
     # 6-10 % of it, the "loss inside the bench" of VERDICT r04 item 9: bench.pipelined_pcie from a bare script gives 11.35 /
     # 13.5 Gsamples/s with 16 batches and 12.67 / 14.9 with 64, tools/pp_bench_fn.py)
-    out["pipelined_pcie"] = pipelined_pcie(torch, cfg, pcm, device, orc, 2048, depth=4, batches=64)
+    # (r06: 1024-frame batches six deep -- finer interleaving of upload, kernels and frame stores: 13.7 / 16.9 Gsamples/s against
+    # 12.6 / 13.9 with 2048-frame batches four deep on one box, tools/pp_scan.py, profiles/r06_pp_scan.json)
+    out["pipelined_pcie"] = pipelined_pcie(torch, cfg, pcm, device, orc, 1024, depth=6, batches=128)
     out["pipelined_pcie"]["batch_8192"] = {k: v for k, v in pipelined_pcie(torch, cfg, pcm, device, orc, FRAMES, depth=3,
                                                                             batches=16).items() if k not in ("link", "note")}
     out["host"] = host_capacity((bps + 7) // 8)   # (after the pipelined leg: its 16 hashing threads use up the CPU quota of the period)
@@ -296,61 +298,99 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                          "byte_identical_to_oracle": True,
                          "note": "median of 5; the stream MD5 is a serial chain on one host thread "
                                  "(encode.rs:571, 1292-1318) and caps a single stream"}
-    # many streams through the C++ front end (flacenc_encode_many): 64 streams of 512 blocks each
+    # ---- many streams, host PCM -> .flac bytes in caller buffers, MD5 included: the two C++ front ends.  Timed: the C entry
+    # point alone on a prepared job array (what a C / Rust caller holds); a pause between calls lets the cgroup's CPU quota
+    # recover (a 30 ms call of a dozen busy threads uses a third of a 100 ms period's quota).
     from flac_codec_amd.encode import BatchEncoder
 
-    n_streams = 64
-    per = pcm[: 512 * BLOCK * C]
-    streams = [per] * n_streams
     usable = int(out["host"]["usable_cpus"])
-    # one writer thread per stream: they sleep while the GPU and the shared MD5 engines work (blocking waits),
-    # so more threads than usable CPUs cost nothing and keep 64 MD5 chains in flight
-    n_threads = min(n_streams, 32)   # (the front end opens all streams at once whatever the thread count; 64 threads on a 16-CPU quota meet the throttle)
-    be = BatchEncoder(opts(), threads=n_threads)
-    views = be.encode(streams, rate, bps, C, copy=False)      # warm-up: lanes, pinned staging, output buffers
-    rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, per, total_known=True)
-    assert rc == 0 and all(v.tobytes() == ref for v in views), "a batch-encoded stream differs from the oracle's .flac"
-    times = []
-    for _ in range(5):
-        t = time.perf_counter()
-        be.encode(streams, rate, bps, C, copy=False)
-        times.append(time.perf_counter() - t)
-    dt = statistics.median(times)
-    out["many_streams"] = {"Msamples/s": round(n_streams * per.size / dt / 1e6, 1), "streams": n_streams,
-                           "frames_per_stream": 512, "host_cores": os.cpu_count(), "host_threads": n_threads,
-                           "byte_identical_to_oracle": True,
-                           "best_Msamples/s": round(n_streams * per.size / min(times) / 1e6, 1),
-                           "note": "median of 5 calls of flacenc_encode_many (C++ front end: all streams open at "
-                                   "once, submit and finish phases claimed by the worker threads, pooled lanes, the streams' MD5 chains on the shared 16-lane "
-                                   "AVX-512 engines, waits that sleep, frames written by k_frame64 straight into pinned host memory); host PCM "
-                                   "-> .flac bytes in caller buffers"}
-    # many SMALL streams: 1024 streams of 8 blocks each (0.7 s of audio), one writer per stream against shared batches
-    # (flacenc_encode_many_coalesced); both compared with each other, one stream with the oracle
+    link = out["pipelined_pcie"]["link"]
+    width = (bps + 7) // 8
+    link_limit = link["h2d_GB/s"] / width * 1e3     # Msamples/s the upload direction alone allows at the stream's width
+
+    def windows(n, f):
+        """n streams of f blocks: windows into the bench's PCM (distinct where it is long enough, overlapping otherwise)"""
+        total = pcm.size // (BLOCK * C)
+        step = max(1, (total - f) // max(1, n - 1)) if n > 1 else 0
+        return [pcm[i * step * BLOCK * C: (i * step + f) * BLOCK * C] for i in range(n)]
+
+    def front_end(streams, coalesce, threads, reps):
+        enc = BatchEncoder(opts(), threads=threads, coalesce=coalesce)
+        h = enc.prepare(streams, rate, bps, C)
+        enc.run(h)                                   # warm-up: contexts, pinned staging, output buffers
+        got = [bytes(v) for v in enc.results(h, copy=False)]
+        ts = []
+        for _ in range(reps):
+            time.sleep(0.05)
+            t = time.perf_counter()
+            enc.run(h)
+            ts.append(time.perf_counter() - t)
+        return got, statistics.median(ts), min(ts)
+
+    def rate_of(n, f, dt):
+        return round(n * f * BLOCK * C / dt / 1e6, 1)
+
+    # 64 streams of 512 blocks each
+    n_streams, f_streams = 64, 512
+    streams = windows(n_streams, f_streams)
+    n_threads = min(n_streams, 16)   # per-stream writers: they mostly wait; more threads than the CPU quota meet the throttle
+    co, co_dt, co_best = front_end(streams, True, 0, 5)
+    pw, pw_dt, pw_best = front_end(streams, False, n_threads, 5)
+    assert co == pw, "the coalescing front end and the per-stream writers disagree"
+    for i in (0, n_streams - 1):
+        rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, streams[i], total_known=True)
+        assert rc == 0 and co[i] == ref, "a batch-encoded stream differs from the oracle's .flac"
+    lane_gbs = md5_lane_rate()
+    chain_bound = n_streams * lane_gbs / width * 1e3 if lane_gbs else None
+    wide = windows(256, 128)
+    _, wide_dt, _ = front_end(wide, True, 0, 5)
+    out["many_streams"] = {
+        "Msamples/s": rate_of(n_streams, f_streams, co_dt), "best_Msamples/s": rate_of(n_streams, f_streams, co_best),
+        "per_stream_writers_Msamples/s": rate_of(n_streams, f_streams, pw_dt), "streams": n_streams, "frames_per_stream": f_streams,
+        "frac_of_link": round(rate_of(n_streams, f_streams, co_dt) / link_limit, 4),
+        "md5_chain_bound_Msamples/s": round(chain_bound, 1) if chain_bound else None,
+        "md5_GB/s_per_chain": lane_gbs,
+        "same_volume_256_streams_Msamples/s": rate_of(256, 128, wide_dt),
+        "same_volume_256_streams_frac_of_link": round(rate_of(256, 128, wide_dt) / link_limit, 4),
+        "host_cores": os.cpu_count(), "usable_cpus": usable, "per_stream_writer_threads": n_threads, "byte_identical_to_oracle": True,
+        "note": "median of 5 calls (C entry point on a prepared job array, 50 ms between calls) of flacenc_encode_many_coalesced -- "
+                "all streams' frames through one ring of pinned staging buffers, stream-width uploads, csrc/host/coalesce.cpp -- and of "
+                "flacenc_encode_many (a writer per stream); host PCM -> .flac bytes in caller buffers, MD5 included.  A stream's "
+                "MD5 is ONE serial chain (encode.rs:571, 1292-1318) whose speed is the latency of its dependent steps "
+                "(md5_GB/s_per_chain, measured here): 64 streams cannot be hashed faster than md5_chain_bound whatever the "
+                "engines' width; the same volume as 256 streams is not bound by it"}
+    # ---- many SMALL streams: 1024 streams of 8 blocks each (0.7 s of audio), and the sweep over stream lengths (8192 blocks
+    # in all): shared batches against one writer per stream, bytes compared
     n_small, f_small = 1024, 8
-    smalls = [pcm[i * 7 * BLOCK * C: (i * 7 + f_small) * BLOCK * C] for i in range(n_small)]
-    if all(x.size == f_small * BLOCK * C for x in smalls):
-        res = {}
-        for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
-            enc = BatchEncoder(opts(), threads=n_threads, **kw)
-            got = [bytes(v) for v in enc.encode(smalls, rate, bps, C, copy=False)]
-            ts = []
-            for _ in range(5):
-                t = time.perf_counter()
-                enc.encode(smalls, rate, bps, C, copy=False)
-                ts.append(time.perf_counter() - t)
-            res[name] = (got, statistics.median(ts))
-        rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, smalls[5], total_known=True)
-        assert rc == 0 and res["coalesced"][0][5] == ref and res["coalesced"][0] == res["one_writer_per_stream"][0]
-        tot = n_small * f_small * BLOCK * C
-        out["many_small_streams"] = {
-            "streams": n_small, "frames_per_stream": f_small,
-            "one_writer_per_stream_Msamples/s": round(tot / res["one_writer_per_stream"][1] / 1e6, 1),
-            "coalesced_Msamples/s": round(tot / res["coalesced"][1] / 1e6, 1),
-            "byte_identical": True,
-            "note": "flacenc_encode_many against flacenc_encode_many_coalesced (runs of whole blocks of several streams in "
-                    "one flacgpu_encode_segments batch), median of 5 calls, host PCM -> .flac bytes, MD5 included; the "
-                    "coalescing front end uploads from the callers' pageable buffers and wins below ~16 blocks per stream "
-                    "(tools/small_streams_probe.py: 256 x 32 blocks 1.1 against 2.3 Gsamples/s, 64 x 512: 2.5 against 7.4)"}
+    smalls = windows(n_small, f_small)
+    co, co_dt, co_best = front_end(smalls, True, 0, 7)
+    pw, pw_dt, _ = front_end(smalls, False, n_threads, 3)
+    rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, smalls[5], total_known=True)
+    assert rc == 0 and co[5] == ref and co == pw
+    sweep = []
+    for f in (1, 2, 4, 16, 32, 64, 128, 256):
+        n = 8192 // f
+        ss = windows(n, f)
+        c_got, c_dt, _ = front_end(ss, True, 0, 5)
+        w_got, w_dt, _ = front_end(ss, False, n_threads, 2 if f < 16 else 3)
+        assert c_got == w_got
+        sweep.append({"streams": n, "blocks": f, "coalesced_Msamples/s": rate_of(n, f, c_dt), "per_stream_writers_Msamples/s": rate_of(n, f, w_dt)})
+    sweep.append({"streams": n_small, "blocks": f_small, "coalesced_Msamples/s": rate_of(n_small, f_small, co_dt),
+                  "per_stream_writers_Msamples/s": rate_of(n_small, f_small, pw_dt)})
+    sweep.append({"streams": n_streams, "blocks": f_streams, "coalesced_Msamples/s": out["many_streams"]["Msamples/s"],
+                  "per_stream_writers_Msamples/s": out["many_streams"]["per_stream_writers_Msamples/s"]})
+    sweep.sort(key=lambda r: r["blocks"])
+    out["many_small_streams"] = {
+        "streams": n_small, "frames_per_stream": f_small,
+        "coalesced_Msamples/s": rate_of(n_small, f_small, co_dt), "coalesced_best_Msamples/s": rate_of(n_small, f_small, co_best),
+        "one_writer_per_stream_Msamples/s": rate_of(n_small, f_small, pw_dt),
+        "coalesced_frac_of_link": round(rate_of(n_small, f_small, co_dt) / link_limit, 4),
+        "stream_length_sweep": sweep,
+        "coalesced_wins_at_every_length": all(r["coalesced_Msamples/s"] >= r["per_stream_writers_Msamples/s"] for r in sweep),
+        "byte_identical": True,
+        "note": "flacenc_encode_many_coalesced against flacenc_encode_many, medians, host PCM -> .flac bytes, MD5 included, bytes "
+                "compared at every length (one stream with the oracle); r05's coalescing front end uploaded int32 from pageable "
+                "memory, one synchronous batch per worker: 1.2-1.3 Gsamples/s at 1024 x 8"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)
     batch = pcm[: 1024 * BLOCK * C]
@@ -381,6 +421,21 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     return out
 
 
+
+
+def md5_lane_rate():
+    """GB/s of ONE MD5 chain inside a full 16-lane group (flacenc_md5_probe): the per-stream bound of the front ends"""
+    import ctypes as C
+
+    from flac_codec_amd import _lib
+
+    L = _lib.lib()
+    if not hasattr(L, "flacenc_md5_probe"):
+        return None
+    L.flacenc_md5_probe.restype = C.c_double
+    L.flacenc_md5_probe.argtypes = [C.c_uint32, C.c_uint32]
+    v = L.flacenc_md5_probe(16, 4096)
+    return round(v / 16, 3) if v > 0 else None
 
 
 SIGNAL_TEXT = {"ar2": "SURVEY 8(d) generator: one Q15 2-pole resonator per channel + dither (the encoder answers with LPC order 2)",
@@ -940,6 +995,20 @@ def compact_record(out, detail_path=None):
     if isinstance(pp, dict):
         extras["pipelined_pcie"] = {k: _pick(pp[k], "Msamples/s", "frac_of_link") for k in ("int32", "packed_3_byte")
                                     if isinstance(pp.get(k), dict)}
+    if isinstance(e2e, dict):   # the feeding paths (host PCM -> .flac bytes, MD5 included) beside the device-resident `value`
+        ms, mss = e2e.get("many_streams"), e2e.get("many_small_streams")
+        fed = {}
+        if isinstance(ms, dict):
+            fed["many_streams"] = _pick(ms, "Msamples/s", "per_stream_writers_Msamples/s", "frac_of_link", "md5_chain_bound_Msamples/s",
+                                        "same_volume_256_streams_Msamples/s", "same_volume_256_streams_frac_of_link")
+        if isinstance(mss, dict):
+            fed["many_small_streams"] = _pick(mss, "coalesced_Msamples/s", "one_writer_per_stream_Msamples/s", "coalesced_frac_of_link",
+                                              "coalesced_wins_at_every_length")
+        one = e2e.get("one_stream")
+        if isinstance(one, dict):
+            fed["one_stream_Msamples/s"] = one.get("Msamples/s")
+        if fed:
+            extras["fed"] = fed
     sc = out.get("shard_counters")
     if isinstance(sc, dict):
         extras["shards"] = _pick(sc, "ranks_seen", "backend", "total_frames", "total_bytes", "min_frame", "max_frame")

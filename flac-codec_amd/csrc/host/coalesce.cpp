@@ -345,8 +345,11 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
             {
                 uint64_t left = total_whole;
                 std::vector<uint32_t> head, tailv;
+                // (not where the streams' MD5 chains bound the call -- a chain makes ~0.2 Gsamples/s, fewer than ~70 streams
+                // cannot use the link --: there the chains only need their bytes EARLY, and every batch costs them a pass)
+                const bool chain_bound = n_active < 70;
                 for (uint32_t z : {batch_cap / 4, batch_cap / 2}) {
-                    if (z >= 64 && left >= 4ull * z) {
+                    if (!chain_bound && z >= 64 && left >= 4ull * z) {
                         head.push_back(z);
                         tailv.push_back(z);
                         left -= 2ull * z;
@@ -459,9 +462,10 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 size_t i0 = 0;
                 uint32_t ntasks = 0;
                 std::vector<Task> ts;
-                // packing tasks: a batch is cut into about as many as there are workers (memory-bound work: no gain from size), 32 ..
+                // packing tasks: a batch is cut into about twice as many as there are workers (memory-bound work: no gain from size; some
+                // workers wait for the GPU or an MD5 chain at any time), 32 ..
                 // 256 frames each
-                const uint32_t fr_target = std::min(256u, std::max(32u, (b.frames + nt - 1) / nt));
+                const uint32_t fr_target = std::min(256u, std::max(32u, (b.frames + 2 * nt - 1) / (2 * nt)));
                 while (i0 < ns) {
                     size_t i1 = i0;
                     uint32_t fr = 0;

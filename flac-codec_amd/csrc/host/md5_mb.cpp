@@ -549,4 +549,30 @@ extern "C" int flacenc_md5_selftest(uint32_t streams, uint32_t runs, uint32_t se
     }
     return bad;
 }
+// Diagnostic (bench.py): GB/s of `lanes` (1..48) independent chains advanced in lockstep on one thread over kib_per_lane KiB
+// each -- divided by the lane count, the speed of ONE chain: the per-stream bound of every front end.
+extern "C" double flacenc_md5_probe(uint32_t lanes, uint32_t kib_per_lane) {
+    using namespace flacenc;
+    if (lanes < 1 || lanes > 48 || kib_per_lane == 0) return 0.0;
+    const size_t per = (size_t)kib_per_lane << 10;
+    std::vector<uint8_t> buf(per * lanes);
+    for (size_t i = 0; i < buf.size(); i++) buf[i] = (uint8_t)(i * 2654435761u >> 11);
+    const int groups = (int)((lanes + 15) / 16);
+    alignas(64) uint32_t st[3][4][16] = {};
+    const uint8_t *ptr[3][16] = {};
+    uint32_t mask[3] = {0, 0, 0};
+    for (uint32_t i = 0; i < lanes; i++) {
+        const int g = (int)(i % groups), l = (int)(i / groups);
+        ptr[g][l] = buf.data() + per * i;
+        mask[g] |= 1u << l;
+    }
+    double best = 0.0;
+    for (int rep = 0; rep < 3; rep++) {
+        const double t0 = now_ms();
+        md5_blocks_groups(st, ptr, per / 64, mask, groups);
+        const double dt = now_ms() - t0;
+        if (dt > 0) best = std::max(best, (double)buf.size() / dt * 1e-6);
+    }
+    return best;
+}
 extern "C" int flacenc_md5_simd_available(void) { return flacenc::Md5Pool::simd_available() ? 1 : 0; }

@@ -251,6 +251,10 @@ int flacenc_streaminfo_bytes(uint32_t min_block, uint32_t max_block, uint32_t mi
  * whether this host runs the 16-lane AVX-512 step. */
 int flacenc_md5_selftest(uint32_t streams, uint32_t runs, uint32_t seed);
 int flacenc_md5_simd_available(void);
+/* Diagnostic: GB/s of `lanes` (1..48) independent MD5 chains advanced in lockstep by one thread over kib_per_lane KiB each;
+ * divided by the lane count it is the speed of ONE chain -- the per-stream bound of every front end (a stream's MD5 is one
+ * serial chain, encode.rs:571, 1292-1318). */
+double flacenc_md5_probe(uint32_t lanes, uint32_t kib_per_lane);
 
 const char *flacenc_last_error(void);
 

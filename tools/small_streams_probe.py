@@ -19,6 +19,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--json", default=None)
+ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--only-coalesced", action="store_true")
 ap.add_argument("shapes", nargs="*", default=["8192x1", "4096x2", "2048x4", "1024x8", "512x16", "256x32", "128x64", "64x128", "64x512"])
 a = ap.parse_args()
 C, B = 2, bench.BLOCK
@@ -31,7 +34,14 @@ for shape in a.shapes:
     rec = {"streams": n, "frames_per_stream": f}
     res = {}
     for name, kw in (("one_writer_per_stream", {}), ("coalesced", {"coalesce": True})):
-        enc = BatchEncoder(Options.best(), threads=a.threads, **kw)
+        if a.only_coalesced and not kw:
+            continue
+        o = Options.best()
+        if kw and a.batch:
+            o = o.batch_frames(a.batch)
+        if kw and a.depth:
+            o = o.pipeline_depth(a.depth)
+        enc = BatchEncoder(o, threads=a.threads, **kw)
         h = enc.prepare(streams, 48000, 24, C)     # the job array a C caller holds; timed: the C entry point alone
         enc.run(h)
         got = [bytes(v) for v in enc.results(h, copy=False)]
@@ -45,7 +55,7 @@ for shape in a.shapes:
                      "Msamples/s": round(n * f * B * C / statistics.median(ts) / 1e6, 1)}
         print(f"{name:24s} {n:5d} x {f:4d} frames: median {statistics.median(ts)*1e3:8.2f} ms  best {min(ts)*1e3:8.2f} ms  "
               f"{n * f * B * C / statistics.median(ts) / 1e6:9.1f} Msamples/s", flush=True)
-    rec["byte_identical"] = res["coalesced"] == res["one_writer_per_stream"]
+    rec["byte_identical"] = a.only_coalesced or res["coalesced"] == res["one_writer_per_stream"]
     print("byte-identical" if rec["byte_identical"] else "BYTES DIFFER", flush=True)
     out.append(rec)
 if a.json:
