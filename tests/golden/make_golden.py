@@ -69,7 +69,28 @@ def build():
     return out
 
 
+def export_inputs(dst):
+    """The cases' PCM as little-endian ceil(bps / 8)-byte samples + manifest.tsv: the input of tools/ref_golden (the reference
+    encoder run by a maintainer with a Rust toolchain)."""
+    os.makedirs(dst, exist_ok=True)
+    rows = ["# name\tpreset\tmax_lpc_order (-1: preset)\tpadding (-1: none)\trate\tbps\tchannels"]
+    for name, preset, ov, rate, bps, ch, pcm in cases():
+        width = (bps + 7) // 8
+        pcm = pcm[: pcm.size - pcm.size % ch]
+        raw = np.ascontiguousarray(pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width]).tobytes()
+        with open(os.path.join(dst, name + ".raw"), "wb") as f:
+            f.write(raw)
+        rows.append("\t".join(str(v) for v in (name, preset, ov.get("max_lpc_order", -1), -1 if ov.get("padding", 0) < 0 else 0,
+                                               rate, bps, ch)))
+    with open(os.path.join(dst, "manifest.tsv"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+    print(f"{len(rows) - 1} inputs written to {dst}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--export-inputs":
+        export_inputs(sys.argv[2])
+        sys.exit(0)
     vec = build()
     with open(os.path.join(HERE, "oracle_vectors.json"), "w") as f:
         json.dump(vec, f, indent=1, sort_keys=True)
