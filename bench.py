@@ -1009,6 +1009,9 @@ def compact_record(out, detail_path=None):
             fed["one_stream_Msamples/s"] = one.get("Msamples/s")
         if fed:
             extras["fed"] = fed
+    if isinstance(out.get("host_to_host"), dict):
+        extras["host_to_host"] = _pick(out["host_to_host"], "Msamples/s", "host_copy_GB/s", "copies_per_output_byte",
+                                       "shard_threads_near_their_gpu", "error")
     sc = out.get("shard_counters")
     if isinstance(sc, dict):
         extras["shards"] = _pick(sc, "ranks_seen", "backend", "total_frames", "total_bytes", "min_frame", "max_frame")
@@ -1123,6 +1126,39 @@ def in_process(args):
             identical += 1
     md.close()
     del bufs
+    # host -> host through flacgpu_multi_encode: pinned PCM of ONE stream (N x F frames at the stream's width), batches of 1024
+    # frames dealt to the shards in turn, every retired batch copied once into its place in `out` -- what the host side moves
+    host_leg = None
+    try:
+        from flac_codec_amd.gpu import PinnedBuffer
+
+        width = (BPS + 7) // 8
+        whole = np.concatenate([pcm[k][0] for k in range(N)])
+        le = np.ascontiguousarray(whole.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width]).reshape(-1)
+        pin = PinnedBuffer(le.size)
+        pin.array[:] = le
+        mh = MultiDevice(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, BPS, C, max_frames=1024, devices=devices, depth=6)
+        body, off, _, _ = mh.encode(pin.array, N * F, BLOCK, 0, RATE, bytes_per_sample=width)      # warm-up + parity
+        for f in (0, N * F - 1):
+            src = pcm[f // F][0][(f % F) * BLOCK * C:((f % F) + 1) * BLOCK * C]
+            rc, fb, _ = orc.encode_frame(oopts, RATE, BPS, np.ascontiguousarray(src.reshape(BLOCK, C).T), frame_number=f)
+            assert rc == 0 and body[off[f]:off[f + 1]] == fb, f"host leg: frame {f} differs from the oracle"
+        o0, c0, _ = mh.host_copy_stats()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            mh.encode_raw(pin.address, N * F, BLOCK, 0, RATE, bytes_per_sample=width)
+            ts.append(time.perf_counter() - t)
+        o1, c1, near = mh.host_copy_stats()
+        dt = statistics.median(ts)
+        host_leg = {"Msamples/s": round(whole.size / dt / 1e6, 1), "frames": N * F, "batch_frames": 1024, "depth": 6,
+                    "bytes_up_per_sample": width, "host_copy_GB/s": round((c1 - c0) / 3 / dt / 1e9, 2),
+                    "copies_per_output_byte": round((c1 - c0) / max(1, o1 - o0), 4), "shard_threads_near_their_gpu": near,
+                    "note": "flacgpu_multi_encode: pinned stream-width PCM in, frames in a pageable caller buffer out; median of 3"}
+        mh.close()
+        pin.close()
+    except Exception as e:   # (diagnostic leg: never costs the contract line)
+        host_leg = {"error": repr(e)}
     # the dominant kernel's roofline on device 0 (one context, kernels back to back), as in the per-rank run
     w = Workload(torch, args.config, F, 0, 1, devices[0], 0, signal=args.signal)
     w.ans[0].encode_device(w.d_pcm[0].data_ptr(), F, BLOCK, 0, RATE, stream=w.streams[0].cuda_stream)
@@ -1153,6 +1189,7 @@ def in_process(args):
         "shard_counters": {"total_frames": merged[0], "total_bytes": merged[1], "min_frame": merged[2],
                            "max_frame": merged[3], "frames_per_rank": [c[0] for c in per_shard], "ranks_seen": N,
                            "backend": "in-process (flacgpu_merge_counters)"},
+        "host_to_host": host_leg,
     }
     print(final_line(out, write_detail(out, args.detail)), flush=True)
 

@@ -224,6 +224,8 @@ def _load():
     L.flacgpu_multi_shards.argtypes = [vp]
     L.flacgpu_multi_shards.restype = C.c_uint32
     L.flacgpu_multi_device_of.argtypes = [vp, C.c_uint32]
+    L.flacgpu_multi_host_copy_stats.argtypes = [vp, u64p, u64p, C.POINTER(C.c_uint32)]
+    L.flacgpu_device_numa_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.flacgpu_multi_encode.argtypes = [vp, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                                        C.c_void_p, C.c_size_t, u64p, u64p, sc, sc]
     L.flacgpu_multi_encode_device.argtypes = [vp, C.c_uint32, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]

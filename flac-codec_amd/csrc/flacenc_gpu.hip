@@ -32,6 +32,7 @@
 #include "checksums.h"
 #include "lpc_host.h"
 
+#include <ctype.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1903,6 +1904,33 @@ int flacgpu_current_device(void) {
     int d = -1;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
 }
+// The host side of a device: the NUMA node its PCI function hangs off and the CPUs local to it (sysfs), for the host threads
+// that feed it (host/multi_device.cpp).  node -1 / an empty list: unknown (no sysfs entry, a single-node machine's -1).
+int flacgpu_device_numa_info(int device, int *numa_node, char *cpulist, size_t cap) {
+    if (numa_node) *numa_node = -1;
+    if (cpulist && cap) cpulist[0] = 0;
+    char bus[64] = {0};
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return FLACGPU_ERR_INVALID_ARG;
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return FLACGPU_ERR_HIP;
+    for (char *p = bus; *p; p++) *p = (char)tolower((unsigned char)*p);   // sysfs spells the address in lower case
+    auto read_line = [&](const char *leaf, char *dst, size_t dcap) {
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/" + leaf;
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return false;
+        const bool ok = fgets(dst, (int)dcap, f) != nullptr;
+        fclose(f);
+        if (ok)
+            for (char *p = dst; *p; p++)
+                if (*p == '\n') *p = 0;
+        return ok;
+    };
+    char tmp[64];
+    if (numa_node && read_line("numa_node", tmp, sizeof tmp)) *numa_node = atoi(tmp);
+    if (cpulist && cap) (void)read_line("local_cpulist", cpulist, cap);
+    return FLACGPU_OK;
+}
+
 int flacgpu_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -6,7 +6,9 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -54,6 +56,14 @@ Rccl &rccl() {
     return r;
 }
 constexpr int kNcclUint64 = 5;
+// the call's device scratch -- the receive area and this rank's record -- kept per device between calls (a hipMalloc /
+// hipFree pair per call is two device-wide synchronisations for a 32-byte exchange); grown when a larger world shows up
+struct Scratch {
+    uint64_t *d = nullptr;
+    size_t records = 0;
+};
+std::mutex g_scratch_mu;
+std::map<int, Scratch> g_scratch;
 }  // namespace
 
 #define RCCL_TRY(expr)                                                                                  \
@@ -96,8 +106,17 @@ int flacgpu_rccl_allgather_counters(void *nccl_comm, void *stream, const flacgpu
     } restore{prev, dev};
     static_assert(sizeof(flacgpu_shard_counters) == 4 * sizeof(uint64_t), "four 64-bit integers per rank");
     const size_t rec = sizeof(flacgpu_shard_counters);
-    uint64_t *d_buf = nullptr;    // [world + 1] records: the receive area, then this rank's record
-    HIP_TRY(hipMalloc(&d_buf, rec * ((size_t)world + 1)));
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);   // (one exchange per process at a time: the scratch is shared)
+    Scratch &sc = g_scratch[dev];
+    if (sc.records < (size_t)world + 1) {
+        if (sc.d) (void)hipFree(sc.d);
+        sc.d = nullptr;
+        sc.records = 0;
+        const size_t want = std::max<size_t>((size_t)world + 1, 65);
+        HIP_TRY(hipMalloc(&sc.d, rec * want));
+        sc.records = want;
+    }
+    uint64_t *d_buf = sc.d;    // [world + 1] records: the receive area, then this rank's record
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = FLACGPU_OK;
     do {
@@ -113,7 +132,6 @@ int flacgpu_rccl_allgather_counters(void *nccl_comm, void *stream, const flacgpu
         if (hipStreamSynchronize(st) != hipSuccess) { rc = FLACGPU_ERR_HIP; break; }
     } while (0);
     if (rc == FLACGPU_ERR_HIP && g_last_error.empty()) g_last_error = "flacgpu_rccl_allgather_counters: HIP copy failed";
-    (void)hipFree(d_buf);
     return rc;
 }
 

@@ -499,8 +499,8 @@ def shard_range_c(total_frames, shards, shard):
 
 
 class MultiDevice:
-    """flacgpu_multi_* (include/flacenc_gpu.h "several GPUs"): one process, one shard per listed device, contiguous frame
-    ranges of one stream per shard, the four-integer records merged on the host.  `devices=None`: every visible device;
+    """flacgpu_multi_* (include/flacenc_gpu.h "several GPUs"): one process, one shard per listed device, batches of
+    contiguous frames of one stream dealt to the shards in turn, the four-integer records merged on the host.  `devices=None`: every visible device;
     an ordinal may be listed more than once (a 1-GPU box then exercises the whole multi-shard path)."""
 
     def __init__(self, block_size, max_partition_order, max_lpc_order, mid_side, exhaustive, window_kind, window_param,
@@ -535,6 +535,38 @@ class MultiDevice:
         if rc:
             raise GpuError(rc, "flacgpu_multi_encode")
         return (buf[: total.value].tobytes(), [int(v) for v in off], [c.as_list() for c in per], merged.as_list())
+
+    def encode_raw(self, address, n_frames, last_frame_len, first_frame_number, sample_rate, bytes_per_sample=4):
+        """flacgpu_multi_encode on a caller-held (pinned) buffer, frames into a reused output array: the timed form."""
+        L = _lib.lib()
+        cap = n_frames * (self.block_size * self.channels * ((self.bits_per_sample + 7) // 8 + 1) + 64)
+        if getattr(self, "_out", None) is None or self._out.size < cap:
+            self._out = np.empty(cap, dtype=np.uint8)
+            self._out[:] = 0      # touched: page faults are not the encoder's
+        total = C.c_uint64(0)
+        rc = L.flacgpu_multi_encode(self._h, C.c_void_p(address), bytes_per_sample, n_frames, last_frame_len, first_frame_number,
+                                    sample_rate, C.c_void_p(self._out.ctypes.data), cap, None, C.byref(total), None, None)
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_encode")
+        return total.value
+
+    def host_copy_stats(self):
+        """(bytes handed out in `out`, bytes the host copied to put them there, shard threads bound near their GPU)"""
+        a, b, n = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        rc = _lib.lib().flacgpu_multi_host_copy_stats(self._h, C.byref(a), C.byref(b), C.byref(n))
+        if rc:
+            raise GpuError(rc, "flacgpu_multi_host_copy_stats")
+        return a.value, b.value, n.value
+
+    @staticmethod
+    def numa_info(device):
+        """(NUMA node of the device's PCI function or -1, its local CPU list as sysfs spells it or '')"""
+        node = C.c_int(-1)
+        buf = C.create_string_buffer(1024)
+        rc = _lib.lib().flacgpu_device_numa_info(device, C.byref(node), buf, 1024)
+        if rc:
+            raise GpuError(rc, "flacgpu_device_numa_info")
+        return node.value, buf.value.decode()
 
     def encode_device(self, shard, device_ptr, n_frames, last_frame_len, first_frame_number, sample_rate,
                       layout=LAYOUT_INTERLEAVED):

@@ -157,8 +157,8 @@ def encode_stream_sharded(pcm, options, sample_rate, bits_per_sample, channels, 
 def encode_stream_multi_device(pcm, options, sample_rate, bits_per_sample, channels, devices=None, batch_frames=1024,
                                depth=2):
     """ONE stream, ONE process, several GPUs (flacgpu_multi_*, include/flacenc_gpu.h): the C ABI cuts the stream's
-    blocks into contiguous frame ranges, one per listed device (`devices=None`: all visible; an ordinal may repeat),
-    merges the four-integer records and hands the frames back in stream order; the owner adds the MD5 and the metadata
+    blocks into batches of contiguous frames dealt to the listed devices in turn (`devices=None`: all visible; an ordinal
+    may repeat), merges the four-integer records and hands the frames back in stream order; the owner adds the MD5 and the metadata
     (flacenc_stream_header).  Returns (.flac bytes, per-shard records, merged record) -- the bytes a single
     FlacSampleWriter produces."""
     import numpy as np

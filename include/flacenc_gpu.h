@@ -402,17 +402,23 @@ int flacgpu_merge_counters(const flacgpu_shard_counters *shards, uint32_t n, fla
 /* The contiguous frame range [lo, hi) of shard `shard` of `shards`: [k F / G, (k + 1) F / G). */
 void flacgpu_shard_range(uint64_t total_frames, uint32_t shards, uint32_t shard, uint64_t *lo, uint64_t *hi);
 int flacgpu_device_count(void);   /* visible HIP devices */
+/* The host side of a device: the NUMA node its PCI function hangs off (-1: unknown) and the CPUs local to it as sysfs spells
+ * them ("0-63,128-191"; empty: unknown) -- where the host threads that feed the device belong. */
+int flacgpu_device_numa_info(int device, int *numa_node, char *cpulist, size_t cap);
 
 /* ONE PROCESS, SEVERAL DEVICES.  `devices` lists HIP ordinals, one shard each (NULL / 0: every visible device; an ordinal
  * may be listed more than once -- each listing is a shard with contexts of its own).  Every shard owns up to `depth`
  * encoder contexts sized for `max_frames` frames per batch.
  *   flacgpu_multi_encode         a run of blocks of ONE stream in host memory (int32, or the little-endian ceil(bps/8)-byte
- *                                samples of flacgpu_encode_packed_async; pinned memory keeps the uploads asynchronous):
- *                                shard k takes frames [lo_k, hi_k) -- any count, cut into batches of <= max_frames through
- *                                a flacgpu_pipeline on its device, one host thread per shard -- with the frame numbers the
- *                                stream gives them; the frames come back concatenated in stream order in `out`,
- *                                `offsets` (n_frames + 1 entries), `per_shard` (flacgpu_multi_shards entries) and `merged`
- *                                as flacgpu_merge_counters leaves them.  Any out pointer may be NULL (FLACGPU_ERR_BUFFER_TOO_SMALL
+ *                                samples of flacgpu_encode_packed_async; pinned memory keeps the uploads asynchronous): cut into
+ *                                batches of <= max_frames frames that are DEALT to the shards in turn (batch j to shard j mod
+ *                                shards), each shard keeping `depth` of its batches in flight on a parked host thread of its own
+ *                                that is bound to the CPUs of its GPU's NUMA node; every frame carries the number the stream
+ *                                gives it.  The frames come back concatenated in stream order in `out` -- each retired batch is
+ *                                copied ONCE, from its pinned slot to its final place (a batch's place is the sum of the sizes of
+ *                                the batches before it, published as they retire) --, `offsets` (n_frames + 1 entries),
+ *                                `per_shard` (flacgpu_multi_shards entries: what each shard encoded) and `merged` as
+ *                                flacgpu_merge_counters leaves them.  Any out pointer may be NULL (FLACGPU_ERR_BUFFER_TOO_SMALL
  *                                with *total set when `out` is too small).  Byte-identical to one context's
  *                                flacgpu_encode_frames over the same blocks.  Synchronous.
  *   flacgpu_multi_encode_device  PCM resident in shard `shard`'s device memory: flacgpu_encode_device on the shard's next
@@ -426,6 +432,9 @@ int flacgpu_multi_create(const flacgpu_options *opts, uint32_t bits_per_sample, 
                          uint32_t n_devices, uint32_t max_frames, uint32_t depth, flacgpu_multi **out);
 void flacgpu_multi_destroy(flacgpu_multi *m);
 uint32_t flacgpu_multi_shards(const flacgpu_multi *m);
+/* Cumulative over the object's flacgpu_multi_encode calls: bytes handed out in `out`, bytes the host copied to put them there
+ * (the same number: one copy per output byte), and how many of the shards' threads were bound to their GPU's local CPUs. */
+int flacgpu_multi_host_copy_stats(const flacgpu_multi *m, uint64_t *bytes_out, uint64_t *bytes_copied, uint32_t *threads_near_gpu);
 int flacgpu_multi_device_of(const flacgpu_multi *m, uint32_t shard);
 int flacgpu_multi_encode(flacgpu_multi *m, const void *pcm, uint32_t bytes_per_sample, uint64_t n_frames,
                          uint32_t last_frame_len, uint64_t first_frame_number, uint32_t sample_rate, uint8_t *out,

@@ -35,7 +35,7 @@ def _single_writer(pcm, o, rate, bps, ch):
                                                         (4, [0, 0, 0], 12, 0), (3, [0, 0, 0], 2, 0)])
 def test_device_listed_several_times_gives_the_single_writers_stream(config, listing, frames, tail):
     from flac_codec_amd.encode import Options
-    from flac_codec_amd.parallel import encode_stream_multi_device, shard_range
+    from flac_codec_amd.parallel import encode_stream_multi_device
 
     cfg = CONFIGS[config]
     ch, bps, rate = cfg["ch"], cfg["bps"], cfg["rate"]
@@ -48,8 +48,11 @@ def test_device_listed_several_times_gives_the_single_writers_stream(config, lis
     rc, ref, _ = orc.encode_stream(oo, rate, bps, ch, pcm, total_known=True)
     assert rc == 0 and data == ref
     n_frames = frames + (1 if tail else 0)
-    assert [c[0] for c in per_shard] == [hi - lo for lo, hi in (shard_range(n_frames, len(listing), k)
-                                                                for k in range(len(listing)))]
+    # batches of 5 frames dealt to the shards in turn (r06): shard k encodes batches k, k + G, ...
+    G, dealt = len(listing), [0] * len(listing)
+    for j, first in enumerate(range(0, n_frames, 5)):
+        dealt[j % G] += min(5, n_frames - first)
+    assert [c[0] for c in per_shard] == dealt
     assert merged[0] == n_frames and merged[1] == sum(c[1] for c in per_shard)
     busy = [c for c in per_shard if c[0]]
     assert merged[2] == min(c[2] for c in busy) and merged[3] == max(c[3] for c in busy)
@@ -70,7 +73,40 @@ def test_packed_samples_and_more_shards_than_frames():
     want, want_off = an.encode_frames(pcm, 3, B, 40, 48000)
     an.close()
     assert body == want and off == want_off
-    assert [c[0] for c in per] == [0, 1, 0, 1, 1] and merged[0] == 3 and merged[2] == min(c[2] for c in per if c[0])
+    # batches of two frames dealt in turn: {0, 1} to shard 0, {2} to shard 1, three idle shards
+    assert [c[0] for c in per] == [2, 1, 0, 0, 0] and merged[0] == 3 and merged[2] == min(c[2] for c in per if c[0])
+
+
+def test_one_host_copy_per_output_byte_and_threads_near_their_gpu():
+    """every retired batch goes from its pinned slot straight to its place in `out` -- the host copies
+    exactly as many bytes as it hands out (r05: three times as many) --, a too-small `out` reports the size and copies only
+    what fits, and the shards' parked threads are bound to their GPU's local CPUs where sysfs names them."""
+    from flac_codec_amd import _lib
+    from flac_codec_amd.gpu import GpuAnalyzer, MultiDevice
+
+    ch, bps, B, F = 2, 24, 4096, 41
+    pcm = synth_fast(7150, ch, bps, B * F)
+    md = MultiDevice(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=4, devices=[0, 0, 0], depth=3)
+    an = GpuAnalyzer(B, 6, 12, True, True, 2, 0.5, bps, ch, max_frames=F)
+    want, want_off = an.encode_frames(pcm, F, B, 9, 48000)
+    an.close()
+    for _ in range(3):
+        body, off, per, merged = md.encode(pcm, F, B, 9, 48000)
+        assert body == want and off == want_off
+    out_b, copied, near = md.host_copy_stats()
+    assert out_b == 3 * len(want) and copied == out_b, (out_b, copied)
+    node, cpus = md.numa_info(0)
+    assert near == (2 if cpus else 0), (near, node, cpus)     # (shard 0 runs on the calling thread)
+    # a buffer that is too small: the total comes back, nothing past the buffer's end is written
+    L = _lib.lib()
+    small = np.zeros(len(want) // 2 + 8, dtype=np.uint8)
+    small[len(want) // 2:] = 0xA5
+    total = C.c_uint64(0)
+    src = np.ascontiguousarray(pcm, dtype=np.int32)
+    rc = L.flacgpu_multi_encode(md._h, C.c_void_p(src.ctypes.data), 4, F, B, 9, 48000, C.c_void_p(small.ctypes.data),
+                                len(want) // 2, None, C.byref(total), None, None)
+    assert rc == -5 and total.value == len(want) and bytes(small[len(want) // 2:]) == b"\xa5" * 8
+    md.close()
 
 
 def test_resident_batches_rotate_through_every_shards_contexts():
