@@ -36,8 +36,6 @@ namespace flacgpu_k {
 bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st) {
     const bool lpc = p.max_lpc_order > 0;
     if (B == FN) {
-        const bool split = kn.cand_split;   // experiment: eight waves per frame (profiles/r03_cand_split.json)
-        if (split && lpc) return launch_cand64_split(p, B, blocks, kn.cand_grid ? kn.cand_grid : 512u, st);
         static std::atomic<uint32_t> res_self[64], res_deep[64], res_lpc[64];
         const uint32_t resident = !lpc ? resident_workgroups(k_cand64p<64, 16, true, true, true>, res_self)
                                   : p.max_lpc_order > 16 ? resident_workgroups(k_cand64p<64, 32, true, true>, res_deep)

@@ -91,7 +91,6 @@ Knobs read_knobs() {
     k.no_frame64 = on("FLACGPU_NO_FRAME64");
     k.no_fork = on("FLACGPU_NO_FORK");
     k.lpc_dyn = on("FLACGPU_LPC_DYN");
-    k.cand_split = on("FLACGPU_CAND_SPLIT");
     k.ac_eight_waves = on("FLACGPU_AC_WAVES8");
     k.cand_persist_n = on("FLACGPU_CAND_PERSIST_N");
     k.early_download = on("FLACGPU_EARLY_DOWNLOAD");

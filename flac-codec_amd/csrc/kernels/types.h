@@ -203,7 +203,7 @@ __host__ __device__ constexpr uint32_t frame_fb_words_exhaustive_stereo(uint32_t
 // when FLACGPU_TEST_KNOBS=1 is set as well.
 struct Knobs {
     bool no_direct = false, no_fast = false, no_w64 = false, no_persist = false, no_ac3 = false, ac_private = false,
-         no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false, cand_split = false,
+         no_fused_pack = false, no_frame64 = false, no_fork = false, lpc_dyn = false,
          ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
@@ -239,8 +239,6 @@ bool launch_cand64(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks
 // cand_direct.hip
 bool launch_cand64_direct(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);   // true: channel choice made
 bool launch_cand64_direct_short(const Params &p, const Knobs &kn, uint32_t B, uint32_t blocks, hipStream_t st);
-// cand_split.hip: eight waves per stereo frame ({L, R, mid, side} x {FIXED, LPC}); false: shape not served
-bool launch_cand64_split(const Params &p, uint32_t B, uint32_t frames, uint32_t grid_cap, hipStream_t st);
 // autocorr.hip
 // returns true when the kernel also ran K4 in its tail (the DIRECT k_autocorr4 instantiations): no launch_lpc then
 bool dispatch_autocorr(uint32_t H, const Params &p, const Knobs &kn, uint32_t frame0, uint32_t nframes, uint32_t n,
