@@ -372,14 +372,17 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 if (st[i]->whole) active.push_back(i);
             }
             for (size_t pi = 0; !active.empty(); pi++) {
-                const uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
+                uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
                 Batch b;
                 // a quantum that lets a batch visit every active stream, but no less than kSolo blocks
                 const uint32_t q = std::max<uint32_t>(kSolo, (uint32_t)((cap + active.size() - 1) / active.size()));
                 while (b.frames < cap && !active.empty()) {
                     const size_t i = active.front();
                     const uint32_t want = (uint32_t)std::min<uint64_t>(q, st[i]->whole - done[i]);
-                    if (want > cap - b.frames && st[i]->solo && b.frames) break;   // a solo stream is never cut: it opens the next batch
+                    if (want > cap - b.frames && st[i]->solo) {   // a solo stream is NEVER cut (its chain is one run, hashed by one task):
+                        if (b.frames) break;                      //   it opens the next batch,
+                        cap = want;                               //   or has a small batch (the plan's remainder) made room (<= kSolo <= batch_cap)
+                    }
                     active.pop_front();
                     const uint32_t n = std::min<uint32_t>(want, cap - b.frames);
                     b.segs.emplace_back(i, done[i], n, b.frames);

@@ -194,6 +194,42 @@ def test_many_small_streams_coalesced_give_each_streams_own_file():
     assert BatchEncoder(o2, threads=3, coalesce=True).encode(mono, 44100, 16, 1) == BatchEncoder(o2, threads=3).encode(mono, 44100, 16, 1)
 
 
+def test_coalesced_shapes_the_packed_upload_cannot_take():
+    """The ring uploads at the stream's width where the device can widen it (whole 16-byte groups per block); otherwise int32
+    goes up and the MD5 bytes are packed beside it -- block sizes that are no multiple of four, 32-bit samples (width 4: the
+    samples ARE the MD5 bytes), 8-bit mono; long streams (cut into segments, chains on the engines) and short ones (one
+    segment, hashed by the workers) in one call, with and without a short last block."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    for o, bps, ch, B in ((Options.default().block_size(1001), 16, 2, 1001), (Options.default(), 32, 2, 4096),
+                          (Options.best(), 8, 1, 4096), (Options.default().block_size(1152), 24, 2, 1152)):
+        cases = []
+        for i in range(12):
+            blocks = (1, 3, 40, 70)[i % 4]
+            n = B * blocks + (0 if i % 3 == 0 else 11 * i + 1)
+            cases.append(synth_fast(8900 + i + bps, ch, bps, n))
+        plain = BatchEncoder(o, threads=4).encode(cases, 44100, bps, ch)
+        co = BatchEncoder(o.batch_frames(128), threads=4, coalesce=True).encode(cases, 44100, bps, ch)
+        assert co == plain, (bps, ch, B)
+
+
+def test_a_short_stream_is_never_cut_by_a_small_batch():
+    """Found by tools/soak/soak_many.py coalesce (r06): a batch closed early in front of a short stream left the plan's small
+    remainder batch at the head of that stream and cut it in two segments -- two HASH tasks then ran ONE MD5 chain from the same
+    state.  A short stream travels whole: seven streams of 8 blocks, one of 7, one of 4 with 64-frame batches (the plan is
+    64 + 3: the four-block stream meets the three-frame batch), every .flac (digest included) the per-stream writers'."""
+    from flac_codec_amd.encode import BatchEncoder, Options
+
+    B = 4096
+    cases = [synth_fast(8950 + i, 2, 24, B * n + 100 * (i % 3)) for i, n in enumerate([8] * 7 + [7, 4])]
+    o = Options.best()
+    plain = BatchEncoder(o, threads=4).encode(cases, 48000, 24, 2)
+    co = BatchEncoder(Options.best().batch_frames(64), threads=6, coalesce=True).encode(cases, 48000, 24, 2)
+    assert co == plain
+    rc, ref, _ = orc.encode_stream(orc.options("best"), 48000, 24, 2, cases[8], total_known=True)
+    assert rc == 0 and co[8] == ref
+
+
 def test_sixty_four_streams_of_512_frames():
     """VERDICT r04 item 6's shape: 64 streams x 512 frames of 24-bit stereo; coalesced == one writer per stream, two of them
     against the oracle."""
