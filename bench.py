@@ -299,8 +299,8 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                          "note": "median of 5; the stream MD5 is a serial chain on one host thread "
                                  "(encode.rs:571, 1292-1318) and caps a single stream"}
     # ---- many streams, host PCM -> .flac bytes in caller buffers, MD5 included: the two C++ front ends.  Timed: the C entry
-    # point alone on a prepared job array (what a C / Rust caller holds); a pause between calls lets the cgroup's CPU quota
-    # recover (a 30 ms call of a dozen busy threads uses a third of a 100 ms period's quota).
+    # point alone on a prepared job array (what a C / Rust caller holds); a pause of one quota period between calls lets the cgroup's
+    # CPU quota recover (a call of a dozen busy threads uses half of a 100 ms period's 16 CPUs; back to back they meet the throttle).
     from flac_codec_amd.encode import BatchEncoder
 
     usable = int(out["host"]["usable_cpus"])
@@ -321,7 +321,7 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         got = [bytes(v) for v in enc.results(h, copy=False)]
         ts = []
         for _ in range(reps):
-            time.sleep(0.05)
+            time.sleep(0.12)   # (a period of the cgroup's CPU quota: every call starts with a full one)
             t = time.perf_counter()
             enc.run(h)
             ts.append(time.perf_counter() - t)
@@ -330,11 +330,17 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     def rate_of(n, f, dt):
         return round(n * f * BLOCK * C / dt / 1e6, 1)
 
+    # (the coalescing front end's legs FIRST: the per-stream writers keep dozens of threads and pooled lanes behind)
+    n_small, f_small = 1024, 8
+    smalls = windows(n_small, f_small)
+    small_co, small_co_dt, small_co_best = front_end(smalls, True, 0, 7)
     # 64 streams of 512 blocks each
     n_streams, f_streams = 64, 512
     streams = windows(n_streams, f_streams)
     n_threads = min(n_streams, 16)   # per-stream writers: they mostly wait; more threads than the CPU quota meet the throttle
     co, co_dt, co_best = front_end(streams, True, 0, 5)
+    wide = windows(256, 128)
+    _, wide_dt, _ = front_end(wide, True, 0, 5)
     pw, pw_dt, pw_best = front_end(streams, False, n_threads, 5)
     assert co == pw, "the coalescing front end and the per-stream writers disagree"
     for i in (0, n_streams - 1):
@@ -342,8 +348,6 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         assert rc == 0 and co[i] == ref, "a batch-encoded stream differs from the oracle's .flac"
     lane_gbs = md5_lane_rate()
     chain_bound = n_streams * lane_gbs / width * 1e3 if lane_gbs else None
-    wide = windows(256, 128)
-    _, wide_dt, _ = front_end(wide, True, 0, 5)
     out["many_streams"] = {
         "Msamples/s": rate_of(n_streams, f_streams, co_dt), "best_Msamples/s": rate_of(n_streams, f_streams, co_best),
         "per_stream_writers_Msamples/s": rate_of(n_streams, f_streams, pw_dt), "streams": n_streams, "frames_per_stream": f_streams,
@@ -353,7 +357,7 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         "same_volume_256_streams_Msamples/s": rate_of(256, 128, wide_dt),
         "same_volume_256_streams_frac_of_link": round(rate_of(256, 128, wide_dt) / link_limit, 4),
         "host_cores": os.cpu_count(), "usable_cpus": usable, "per_stream_writer_threads": n_threads, "byte_identical_to_oracle": True,
-        "note": "median of 5 calls (C entry point on a prepared job array, 50 ms between calls) of flacenc_encode_many_coalesced -- "
+        "note": "median of 5 calls (C entry point on a prepared job array, 120 ms between calls) of flacenc_encode_many_coalesced -- "
                 "all streams' frames through one ring of pinned staging buffers, stream-width uploads, csrc/host/coalesce.cpp -- and of "
                 "flacenc_encode_many (a writer per stream); host PCM -> .flac bytes in caller buffers, MD5 included.  A stream's "
                 "MD5 is ONE serial chain (encode.rs:571, 1292-1318) whose speed is the latency of its dependent steps "
@@ -361,14 +365,12 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
                 "engines' width; the same volume as 256 streams is not bound by it"}
     # ---- many SMALL streams: 1024 streams of 8 blocks each (0.7 s of audio), and the sweep over stream lengths (8192 blocks
     # in all): shared batches against one writer per stream, bytes compared
-    n_small, f_small = 1024, 8
-    smalls = windows(n_small, f_small)
-    co, co_dt, co_best = front_end(smalls, True, 0, 7)
+    co, co_dt, co_best = small_co, small_co_dt, small_co_best
     pw, pw_dt, _ = front_end(smalls, False, n_threads, 3)
     rc, ref, _ = orc.encode_stream(orc_options(orc, cfg), rate, bps, C, smalls[5], total_known=True)
     assert rc == 0 and co[5] == ref and co == pw
     sweep = []
-    for f in (1, 2, 4, 16, 32, 64, 128, 256):
+    for f in (1, 2, 4, 16, 32, 64, 128, 256, 512):
         n = 8192 // f
         ss = windows(n, f)
         c_got, c_dt, _ = front_end(ss, True, 0, 5)

@@ -19,6 +19,8 @@ public:
     // for the multi-buffer engine (md5_mb.cpp): one block on a bare state, the state words of this
     // object, and whole blocks hashed outside update() (only while no partial block is buffered)
     static void transform(uint32_t state[4], const uint8_t *p);
+    // nblocks blocks of TWO independent chains, interleaved (a chain is latency-bound: the second one is almost free)
+    static void transform2(uint32_t s0[4], const uint8_t *p0, uint32_t s1[4], const uint8_t *p1, size_t nblocks);
     void get_state(uint32_t s[4]) const { s[0] = a_; s[1] = b_; s[2] = c_; s[3] = d_; }
     void set_state(const uint32_t s[4]) { a_ = s[0]; b_ = s[1]; c_ = s[2]; d_ = s[3]; }
     void add_blocks(uint64_t nblocks) { len_ += 64 * nblocks; }

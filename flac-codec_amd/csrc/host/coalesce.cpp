@@ -200,38 +200,6 @@ struct Task {
 
 }  // namespace
 
-// CPUs this process may really use: the cgroup's CPU quota (a container with 16 CPUs' worth of time on a 256-thread host
-// is throttled for the rest of the period once its threads have burnt the quota -- more runnable threads than that only add
-// stalls), else the hardware threads
-namespace flacenc_host {
-unsigned usable_cpus() {
-    static const unsigned n = [] {
-        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
-            char q[32] = {0};
-            long period = 0;
-            if (std::fscanf(f, "%31s %ld", q, &period) == 2 && q[0] != 'm' && period > 0) {
-                const long quota = std::atol(q);
-                if (quota > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long>(1, (quota + period / 2) / period));
-            }
-            std::fclose(f);
-        } else {
-            long quota = -1, period = 0;
-            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-                if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
-                std::fclose(g);
-            }
-            if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (std::fscanf(g, "%ld", &period) != 1) period = 0;
-                std::fclose(g);
-            }
-            if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long>(1, (quota + period / 2) / period));
-        }
-        return hw;
-    }();
-    return n;
-}
-}  // namespace flacenc_host
 static double cpu_ms() {   // user + system time of the whole process
     rusage r;
     getrusage(RUSAGE_SELF, &r);
@@ -355,6 +323,15 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                         left -= 2ull * z;
                     }
                 }
+                // (chain-bound: ONE small batch in front -- a few blocks of every stream, packed in a tenth of a millisecond --
+                // starts all the chains together; a full first batch starts the last of them a millisecond late)
+                if (chain_bound && n_active && left >= 4ull * batch_cap) {
+                    const uint32_t z = (uint32_t)std::min<uint64_t>(batch_cap / 4, 8ull * n_active);
+                    if (z >= 8) {
+                        head.push_back(z);
+                        left -= z;
+                    }
+                }
                 plan = head;
                 while (left) {
                     const uint32_t z = (uint32_t)std::min<uint64_t>(left, batch_cap);
@@ -375,10 +352,13 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
                 uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
                 Batch b;
                 // a quantum that lets a batch visit every active stream, but no less than kSolo blocks
-                const uint32_t q = std::max<uint32_t>(kSolo, (uint32_t)((cap + active.size() - 1) / active.size()));
+                // (solo streams are taken whole whatever the quantum; the floor keeps a long stream's segments from getting tiny --
+                // except in the small batch a chain-bound call starts with)
+                const uint32_t q_floor = (pi == 0 && n_active < 70 && cap < batch_cap) ? 1u : kSolo;
+                const uint32_t q = std::max<uint32_t>(q_floor, (uint32_t)((cap + active.size() - 1) / active.size()));
                 while (b.frames < cap && !active.empty()) {
                     const size_t i = active.front();
-                    const uint32_t want = (uint32_t)std::min<uint64_t>(q, st[i]->whole - done[i]);
+                    const uint32_t want = st[i]->solo ? (uint32_t)st[i]->whole : (uint32_t)std::min<uint64_t>(q, st[i]->whole - done[i]);
                     if (want > cap - b.frames && st[i]->solo) {   // a solo stream is NEVER cut (its chain is one run, hashed by one task):
                         if (b.frames) break;                      //   it opens the next batch,
                         cap = want;                               //   or has a small batch (the plan's remainder) made room (<= kSolo <= batch_cap)

@@ -2,6 +2,7 @@
 // See md5_mb.h.  RFC 1321 is restated here only as its step function on sixteen independent 32-bit lanes;
 // the result is the scalar one word for word (host/checksums.cpp keeps padding and length handling).
 #include "md5_mb.h"
+#include "host_internal.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -352,7 +353,7 @@ struct Md5Engine {
                     work[nw++] = act[i];
                     common = std::min(common, act[i]->blocks);
                 }
-            if (nw >= 2 && Md5Pool::simd_available()) {
+            if (nw >= 3 && Md5Pool::simd_available()) {
                 // lanes dealt round the groups: every group about equally full
                 const int groups = (nw + kLanes - 1) / kLanes;
                 const uint8_t *ptr[kGroups][kLanes];
@@ -372,6 +373,21 @@ struct Md5Engine {
                     const int g = i % groups, l = i / groups;
                     const uint32_t w4[4] = {st[g][0][l], st[g][1][l], st[g][2][l], st[g][3][l]};
                     work[i]->md5->set_state(w4);
+                    work[i]->md5->add_blocks(common);
+                    work[i]->p += 64 * common;
+                    work[i]->blocks -= common;
+                }
+            } else if (nw == 2) {
+                // TWO chains: the scalar code with both interleaved in one instruction stream (Md5::transform2) -- each runs
+                // at the scalar chain's speed (1.05 GB/s on the bench host, a SIMD lane 0.6): what a handful of long streams
+                // spread two to an engine get
+                uint32_t s0[4], s1[4];
+                work[0]->md5->get_state(s0);
+                work[1]->md5->get_state(s1);
+                Md5::transform2(s0, work[0]->p, s1, work[1]->p, common);
+                work[0]->md5->set_state(s0);
+                work[1]->md5->set_state(s1);
+                for (int i = 0; i < 2; i++) {
                     work[i]->md5->add_blocks(common);
                     work[i]->p += 64 * common;
                     work[i]->blocks -= common;
@@ -410,6 +426,8 @@ struct Md5Pool::Impl {
 };
 
 Md5Pool::Md5Pool() : impl_(new Impl) {
+    // half the CPUs the process may use (its cgroup quota), four to eight
+    impl_->max_engines = std::min(8u, std::max(4u, flacenc_host::usable_cpus() / 2));
     if (const char *e = std::getenv("FLACENC_MD5_ENGINES")) impl_->max_engines = (unsigned)std::max(1, std::atoi(e));
 }
 Md5Pool::~Md5Pool() {
@@ -430,22 +448,25 @@ Md5Pool &Md5Pool::get() {
 
 Md5Lane *Md5Pool::attach(Md5 *state) {
     std::lock_guard<std::mutex> plock(impl_->mu);
-    // an engine fills its 16 lanes before the next engine thread is started; after that the least loaded
+    // Streams are SPREAD: an engine is given two (a pair runs on the scalar code at 1.05 GB/s per chain, where a lane of the
+    // lockstep SIMD step makes 0.6), then the next engine thread is started; once every engine the pool may have is running,
+    // a newcomer joins the one with the fewest streams -- a handful of long streams get scalar speed, hundreds fill the
+    // engines' three lockstep groups evenly.  (Idle engines sleep: their number costs nothing but when they work.)
     Md5Engine *best = nullptr;
+    size_t best_n = 0;
     for (auto &e : impl_->engines) {
         std::lock_guard<std::mutex> lock(e->mu);
-        if (e->lanes.size() < (size_t)Md5Engine::kLanes && (!best || e->lanes.size() > best->lanes.size())) best = e.get();
+        const size_t n = e->lanes.size();
+        if (!best || n < best_n) {
+            best = e.get();
+            best_n = n;
+        }
     }
-    if (!best && impl_->engines.size() < impl_->max_engines) {
+    if ((!best || best_n >= 2) && impl_->engines.size() < impl_->max_engines) {
         impl_->engines.emplace_back(new Md5Engine());
         best = impl_->engines.back().get();
         best->th = std::thread([best] { best->run(); });
     }
-    if (!best)
-        for (auto &e : impl_->engines) {
-            std::lock_guard<std::mutex> lock(e->mu);
-            if (!best || e->lanes.size() < best->lanes.size()) best = e.get();
-        }
     if (!best) return nullptr;
     Md5Lane *l = new Md5Lane();
     l->engine = best;

@@ -2,7 +2,7 @@
 // the 16-lane MD5 step, each on 1..T threads at once (aggregate GB/s).  The many-stream front ends
 // (flacenc_encode_many*, csrc/host/stream_writer.cpp) are bound by these and by the CPU quota of the cgroup.
 //   g++ -O3 -std=c++17 -Iflac-codec_amd/csrc -Iflac-codec_amd/csrc/host tools/ubench/host_feed_bench.cpp \
-//       flac-codec_amd/csrc/host/md5_mb.cpp flac-codec_amd/csrc/host/checksums.cpp -lpthread -o tools/ubench/bin/host_feed_bench
+//       flac-codec_amd/csrc/host/md5_mb.cpp flac-codec_amd/csrc/host/checksums.cpp flac-codec_amd/csrc/host/cpu_quota.cpp -lpthread -o tools/ubench/bin/host_feed_bench
 #include <immintrin.h>
 
 #include <atomic>

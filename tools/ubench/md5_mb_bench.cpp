@@ -1,5 +1,5 @@
 // Throughput of the 16-lane MD5 step (csrc/host/md5_mb.cpp) against the scalar chain on this host:
-//   g++ -O2 -std=c++17 -Iflac-codec_amd/csrc -Iflac-codec_amd/csrc/host tools/ubench/md5_mb_bench.cpp flac-codec_amd/csrc/host/md5_mb.cpp flac-codec_amd/csrc/host/checksums.cpp -lpthread -o /tmp/md5_mb_bench
+//   g++ -O2 -std=c++17 -Iflac-codec_amd/csrc -Iflac-codec_amd/csrc/host tools/ubench/md5_mb_bench.cpp flac-codec_amd/csrc/host/md5_mb.cpp flac-codec_amd/csrc/host/checksums.cpp flac-codec_amd/csrc/host/cpu_quota.cpp -lpthread -o /tmp/md5_mb_bench
 #include "host/md5_mb.h"
 #include <chrono>
 #include <cstdio>
