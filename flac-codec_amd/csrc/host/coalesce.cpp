@@ -215,7 +215,126 @@ static bool trace_on() {
     return on;
 }
 
+// frames per batch: the options' batch_frames (at least 64), else about 16 Mi samples; never more than the group holds
+static uint32_t coalesce_batch_cap(uint32_t batch_frames, size_t samples_per_block, uint64_t total_whole) {
+    uint32_t cap = batch_frames ? std::max(batch_frames, 64u) : (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(64, (16u << 20) / samples_per_block));
+    return (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(total_whole, 1));
+}
+
+// ---- the batches of one shape group: which run of whole blocks of which stream goes into which batch ---------------------------
+// `whole[k]` = whole blocks of stream k; batch_cap = frames a slot's context takes.  Invariants (tests/test_coalesce_plan.py):
+// every block of every stream exactly once, a stream's segments in stream order and in non-decreasing batches, no batch above
+// batch_cap, and a stream of up to kSolo blocks in ONE segment (its MD5 chain is one run hashed by one task).
+struct PlanSeg {
+    uint32_t stream;   // index into `whole`
+    uint64_t first;    // first block of the segment in its stream
+    uint32_t n;        // blocks
+};
+static std::vector<std::vector<PlanSeg>> plan_batches(const std::vector<uint64_t> &whole, uint32_t batch_cap) {
+    uint64_t total_whole = 0;
+    size_t n_active = 0;
+    for (uint64_t w : whole) {
+        total_whole += w;
+        n_active += w ? 1 : 0;
+    }
+    std::vector<std::vector<PlanSeg>> batches;
+    if (!total_whole || !batch_cap) return batches;
+    // batch sizes: the first and the last ones smaller (a quarter, a half of the cap) -- the first upload starts after a
+    // quarter of a batch has been packed, and behind the last upload only a quarter of a batch is left to analyse,
+    // assemble and copy
+    std::vector<uint32_t> plan;
+    {
+        uint64_t left = total_whole;
+        std::vector<uint32_t> head, tailv;
+        // (not where the streams' MD5 chains bound the call -- a chain makes ~0.2 Gsamples/s, fewer than ~70 streams
+        // cannot use the link --: there the chains only need their bytes EARLY, and every batch costs them a pass)
+        const bool chain_bound = n_active < 70;
+        for (uint32_t z : {batch_cap / 4, batch_cap / 2}) {
+            if (!chain_bound && z >= 64 && left >= 4ull * z) {
+                head.push_back(z);
+                tailv.push_back(z);
+                left -= 2ull * z;
+            }
+        }
+        // (chain-bound: ONE small batch in front -- a few blocks of every stream, packed in a tenth of a millisecond --
+        // starts all the chains together; a full first batch starts the last of them a millisecond late)
+        if (chain_bound && n_active && left >= 4ull * batch_cap) {
+            const uint32_t z = (uint32_t)std::min<uint64_t>(batch_cap / 4, 8ull * n_active);
+            if (z >= 8) {
+                head.push_back(z);
+                left -= z;
+            }
+        }
+        plan = head;
+        while (left) {
+            const uint32_t z = (uint32_t)std::min<uint64_t>(left, batch_cap);
+            plan.push_back(z);
+            left -= z;
+        }
+        for (size_t i = tailv.size(); i-- > 0;) plan.push_back(tailv[i]);
+    }
+    std::vector<uint64_t> done(whole.size(), 0);
+    std::deque<uint32_t> active;
+    for (size_t k = 0; k < whole.size(); k++)
+        if (whole[k]) active.push_back((uint32_t)k);
+    for (size_t pi = 0; !active.empty(); pi++) {
+        uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
+        std::vector<PlanSeg> b;
+        uint32_t frames = 0;
+        // a quantum that lets a batch visit every active stream, but no less than kSolo blocks (solo streams are taken whole
+        // whatever the quantum; the floor keeps a long stream's segments from getting tiny -- except in the small batch a
+        // chain-bound call starts with)
+        const uint32_t q_floor = (pi == 0 && n_active < 70 && cap < batch_cap) ? 1u : kSolo;
+        const uint32_t q = std::max<uint32_t>(q_floor, (uint32_t)((cap + active.size() - 1) / active.size()));
+        while (frames < cap && !active.empty()) {
+            const uint32_t k = active.front();
+            const bool solo = whole[k] <= kSolo;
+            const uint32_t want = solo ? (uint32_t)whole[k] : (uint32_t)std::min<uint64_t>(q, whole[k] - done[k]);
+            if (want > cap - frames && solo) {   // a solo stream is NEVER cut (its chain is one run, hashed by one task):
+                if (frames) break;               //   it opens the next batch,
+                cap = want;                      //   or has a small batch (the plan's remainder) made room (<= kSolo <= batch_cap)
+            }
+            active.pop_front();
+            const uint32_t n = std::min<uint32_t>(want, cap - frames);
+            b.push_back(PlanSeg{k, done[k], n});
+            frames += n;
+            done[k] += n;
+            if (done[k] < whole[k]) {
+                if (n < want) active.push_front(k);   // (cut by the batch's end: it goes on first in the next one)
+                else active.push_back(k);
+            }
+        }
+        batches.push_back(std::move(b));
+    }
+    return batches;
+}
+
 extern "C" {
+
+// Test hook (tests/test_coalesce_plan.py): the batch plan of a shape group as flat arrays -- segment i is blocks
+// [seg_first[i], seg_first[i] + seg_n[i]) of stream seg_stream[i] in batch seg_batch[i].  Returns the number of segments (the
+// arrays hold up to `cap`), *batch_cap_out the frames per batch the front end would size its contexts for.
+size_t flacenc_coalesce_plan(const uint64_t *whole, size_t n_streams, uint32_t batch_frames, uint32_t samples_per_block, uint32_t *seg_stream,
+                             uint64_t *seg_first, uint32_t *seg_n, uint32_t *seg_batch, size_t cap, uint32_t *batch_cap_out) {
+    std::vector<uint64_t> w(whole, whole + n_streams);
+    uint64_t total = 0;
+    for (uint64_t v : w) total += v;
+    const uint32_t bc = coalesce_batch_cap(batch_frames, samples_per_block ? samples_per_block : 1, total);
+    if (batch_cap_out) *batch_cap_out = bc;
+    size_t n = 0;
+    const auto plan = plan_batches(w, bc);
+    for (size_t b = 0; b < plan.size(); b++)
+        for (const PlanSeg &g : plan[b]) {
+            if (n < cap) {
+                seg_stream[n] = g.stream;
+                seg_first[n] = g.first;
+                seg_n[n] = g.n;
+                seg_batch[n] = (uint32_t)b;
+            }
+            n++;
+        }
+    return n;
+}
 
 void flacenc_release_pools(void) {
     RingPool::get().release_all();
@@ -297,80 +416,25 @@ int flacenc_encode_many_coalesced(const flacenc_options *opts_in, flacenc_job *j
 
         // ---- batches: about 16 Mi samples each, the streams taken in turn, a quantum of whole blocks at a time
         uint64_t total_whole = 0;
-        size_t n_active = 0;
-        for (size_t i : ids) {
-            total_whole += st[i]->whole;
-            n_active += st[i]->whole ? 1 : 0;
-        }
-        uint32_t batch_cap = o.batch_frames ? std::max(o.batch_frames, 64u) : (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(64, (16u << 20) / per));
-        batch_cap = (uint32_t)std::min<uint64_t>(batch_cap, std::max<uint64_t>(total_whole, 1));
+        for (size_t i : ids) total_whole += st[i]->whole;
+        const uint32_t batch_cap = coalesce_batch_cap(o.batch_frames, per, total_whole);
         std::vector<Batch> batches;
         {
-            // batch sizes: the first and the last ones smaller (a quarter, a half of the cap) -- the first upload starts after a
-            // quarter of a batch has been packed, and behind the last upload only a quarter of a batch is left to analyse,
-            // assemble and copy
-            std::vector<uint32_t> plan;
-            {
-                uint64_t left = total_whole;
-                std::vector<uint32_t> head, tailv;
-                // (not where the streams' MD5 chains bound the call -- a chain makes ~0.2 Gsamples/s, fewer than ~70 streams
-                // cannot use the link --: there the chains only need their bytes EARLY, and every batch costs them a pass)
-                const bool chain_bound = n_active < 70;
-                for (uint32_t z : {batch_cap / 4, batch_cap / 2}) {
-                    if (!chain_bound && z >= 64 && left >= 4ull * z) {
-                        head.push_back(z);
-                        tailv.push_back(z);
-                        left -= 2ull * z;
-                    }
-                }
-                // (chain-bound: ONE small batch in front -- a few blocks of every stream, packed in a tenth of a millisecond --
-                // starts all the chains together; a full first batch starts the last of them a millisecond late)
-                if (chain_bound && n_active && left >= 4ull * batch_cap) {
-                    const uint32_t z = (uint32_t)std::min<uint64_t>(batch_cap / 4, 8ull * n_active);
-                    if (z >= 8) {
-                        head.push_back(z);
-                        left -= z;
-                    }
-                }
-                plan = head;
-                while (left) {
-                    const uint32_t z = (uint32_t)std::min<uint64_t>(left, batch_cap);
-                    plan.push_back(z);
-                    left -= z;
-                }
-                for (size_t i = tailv.size(); i-- > 0;) plan.push_back(tailv[i]);
+            std::vector<uint64_t> whole_of(ids.size());
+            for (size_t k = 0; k < ids.size(); k++) whole_of[k] = st[ids[k]]->whole;
+            const std::vector<std::vector<PlanSeg>> plan = plan_batches(whole_of, batch_cap);
+            for (size_t k = 0; k < ids.size(); k++) {
+                // streams of up to kSolo blocks travel as ONE segment and are hashed by HASH tasks (below)
+                st[ids[k]]->solo = whole_of[k] && whole_of[k] <= kSolo;
+                st[ids[k]]->attach_tried = whole_of[k] <= kSolo;   // (no engine lane: their short last block is hashed where it is packed)
             }
-            std::vector<uint64_t> done(n_jobs, 0);
-            std::deque<size_t> active;
-            for (size_t i : ids) {
-                // streams of up to kSolo blocks travel as ONE segment and are hashed by the worker that packs them (below)
-                st[i]->solo = st[i]->whole && st[i]->whole <= kSolo;
-                st[i]->attach_tried = st[i]->whole <= kSolo;   // (no engine lane: their short last block is hashed where it is packed)
-                if (st[i]->whole) active.push_back(i);
-            }
-            for (size_t pi = 0; !active.empty(); pi++) {
-                uint32_t cap = pi < plan.size() ? plan[pi] : batch_cap;   // (batches closed early in front of a solo stream: more of them)
+            for (const auto &pb : plan) {
                 Batch b;
-                // a quantum that lets a batch visit every active stream, but no less than kSolo blocks
-                // (solo streams are taken whole whatever the quantum; the floor keeps a long stream's segments from getting tiny --
-                // except in the small batch a chain-bound call starts with)
-                const uint32_t q_floor = (pi == 0 && n_active < 70 && cap < batch_cap) ? 1u : kSolo;
-                const uint32_t q = std::max<uint32_t>(q_floor, (uint32_t)((cap + active.size() - 1) / active.size()));
-                while (b.frames < cap && !active.empty()) {
-                    const size_t i = active.front();
-                    const uint32_t want = st[i]->solo ? (uint32_t)st[i]->whole : (uint32_t)std::min<uint64_t>(q, st[i]->whole - done[i]);
-                    if (want > cap - b.frames && st[i]->solo) {   // a solo stream is NEVER cut (its chain is one run, hashed by one task):
-                        if (b.frames) break;                      //   it opens the next batch,
-                        cap = want;                               //   or has a small batch (the plan's remainder) made room (<= kSolo <= batch_cap)
-                    }
-                    active.pop_front();
-                    const uint32_t n = std::min<uint32_t>(want, cap - b.frames);
-                    b.segs.emplace_back(i, done[i], n, b.frames);
-                    b.frames += n;
-                    done[i] += n;
-                    if (done[i] == st[i]->whole) st[i]->last_batch = batches.size();
-                    else if (n < want) active.push_front(i);   // (cut by the batch's end: it goes on first in the next one)
-                    else active.push_back(i);
+                for (const PlanSeg &g : pb) {
+                    const size_t i = ids[g.stream];
+                    b.segs.emplace_back(i, g.first, g.n, b.frames);
+                    b.frames += g.n;
+                    if (g.first + g.n == st[i]->whole) st[i]->last_batch = batches.size();
                 }
                 batches.push_back(std::move(b));
             }

@@ -255,6 +255,12 @@ int flacenc_md5_simd_available(void);
  * divided by the lane count it is the speed of ONE chain -- the per-stream bound of every front end (a stream's MD5 is one
  * serial chain, encode.rs:571, 1292-1318). */
 double flacenc_md5_probe(uint32_t lanes, uint32_t kib_per_lane);
+/* Test hook of flacenc_encode_many_coalesced's batch planning (host/coalesce.cpp, tests/test_coalesce_plan.py): streams of
+ * whole[k] whole blocks of one shape (samples_per_block = block size x channels), batch_frames as in flacenc_options (0: the
+ * default) -> segment i is blocks [seg_first[i], seg_first[i] + seg_n[i]) of stream seg_stream[i] in batch seg_batch[i].
+ * Returns the number of segments (the arrays hold up to `cap`); *batch_cap: the frames a batch may hold. */
+size_t flacenc_coalesce_plan(const uint64_t *whole, size_t n_streams, uint32_t batch_frames, uint32_t samples_per_block, uint32_t *seg_stream,
+                             uint64_t *seg_first, uint32_t *seg_n, uint32_t *seg_batch, size_t cap, uint32_t *batch_cap);
 
 const char *flacenc_last_error(void);
 
