@@ -327,6 +327,26 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
             ts.append(time.perf_counter() - t)
         return got, statistics.median(ts), min(ts)
 
+    def front_end_pair(streams, threads, reps, rounds=3):
+        """Both front ends on the same streams, their calls in alternating rounds (the host legs move by a quarter from minute to
+        minute on a shared host: a comparison needs both sides under the same weather); medians over all rounds."""
+        encs = [BatchEncoder(opts(), threads=0, coalesce=True), BatchEncoder(opts(), threads=threads, coalesce=False)]
+        hs = [e.prepare(streams, rate, bps, C) for e in encs]
+        gots = []
+        for e, h in zip(encs, hs):
+            e.run(h)
+            gots.append([bytes(v) for v in e.results(h, copy=False)])
+        assert gots[0] == gots[1], "the coalescing front end and the per-stream writers disagree"
+        ts = ([], [])
+        for _ in range(rounds):
+            for k in (0, 1):
+                for _ in range(reps[k]):
+                    time.sleep(0.12)
+                    t = time.perf_counter()
+                    encs[k].run(hs[k])
+                    ts[k].append(time.perf_counter() - t)
+        return statistics.median(ts[0]), statistics.median(ts[1])
+
     def rate_of(n, f, dt):
         return round(n * f * BLOCK * C / dt / 1e6, 1)
 
@@ -373,14 +393,11 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
     for f in (1, 2, 4, 16, 32, 64, 128, 256, 512):
         n = 8192 // f
         ss = windows(n, f)
-        c_got, c_dt, _ = front_end(ss, True, 0, 5)
-        w_got, w_dt, _ = front_end(ss, False, n_threads, 2 if f < 16 else 3)
-        assert c_got == w_got
+        c_dt, w_dt = front_end_pair(ss, n_threads, (3, 1 if f < 16 else 2))
         sweep.append({"streams": n, "blocks": f, "coalesced_Msamples/s": rate_of(n, f, c_dt), "per_stream_writers_Msamples/s": rate_of(n, f, w_dt)})
-    sweep.append({"streams": n_small, "blocks": f_small, "coalesced_Msamples/s": rate_of(n_small, f_small, co_dt),
-                  "per_stream_writers_Msamples/s": rate_of(n_small, f_small, pw_dt)})
-    sweep.append({"streams": n_streams, "blocks": f_streams, "coalesced_Msamples/s": out["many_streams"]["Msamples/s"],
-                  "per_stream_writers_Msamples/s": out["many_streams"]["per_stream_writers_Msamples/s"]})
+    for n, f, ss in ((n_small, f_small, smalls), (n_streams, f_streams, streams)):
+        c_dt, w_dt = front_end_pair(ss, n_threads, (3, 2))
+        sweep.append({"streams": n, "blocks": f, "coalesced_Msamples/s": rate_of(n, f, c_dt), "per_stream_writers_Msamples/s": rate_of(n, f, w_dt)})
     sweep.sort(key=lambda r: r["blocks"])
     out["many_small_streams"] = {
         "streams": n_small, "frames_per_stream": f_small,
@@ -390,8 +407,9 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         "stream_length_sweep": sweep,
         "coalesced_wins_at_every_length": all(r["coalesced_Msamples/s"] >= r["per_stream_writers_Msamples/s"] for r in sweep),
         "byte_identical": True,
-        "note": "flacenc_encode_many_coalesced against flacenc_encode_many, medians, host PCM -> .flac bytes, MD5 included, bytes "
-                "compared at every length (one stream with the oracle); r05's coalescing front end uploaded int32 from pageable "
+        "note": "flacenc_encode_many_coalesced against flacenc_encode_many, host PCM -> .flac bytes, MD5 included, bytes "
+                "compared at every length (one stream with the oracle); the sweep's rows: both front ends' calls in three alternating "
+                "rounds on the same streams, medians over the rounds (9 and 3-6 calls); r05's coalescing front end uploaded int32 from pageable "
                 "memory, one synchronous batch per worker: 1.2-1.3 Gsamples/s at 1024 x 8"}
     # PCIe-inclusive batch call: H2D + kernels + D2H, no MD5 / container
     an = GpuAnalyzer(BLOCK, cfg["po"], cfg["lpc"], True, True, 2, 0.5, bps, C, max_frames=1024, device=device)

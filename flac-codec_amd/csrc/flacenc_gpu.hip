@@ -81,6 +81,7 @@ Knobs read_knobs() {
     k.no_ac_fma = on("FLACGPU_NO_AC_FMA");
     k.lpc_fuse_deep = on("FLACGPU_LPC_FUSE_DEEP");
     k.upload_by_kernel = on("FLACGPU_UPLOAD_KERNEL");
+    k.no_hand = on("FLACGPU_NO_HAND");   // A/B: k_frame64 fetches the samples and runs the FIR again (Params::hand_meta off)
     k.no_direct_short = on("FLACGPU_NO_DIRECT_SHORT");   // A/B: the shorter wave block lengths through K0 + k_cand64
     k.no_fast = on("FLACGPU_NO_FAST");
     k.no_w64 = on("FLACGPU_NO_W64");
@@ -135,6 +136,7 @@ struct flacgpu_ctx {
     SubPlan *d_fixed = nullptr, *d_cand = nullptr, *d_out = nullptr;
     LpcParams *d_lpc = nullptr;
     FrameInfo *d_finfo = nullptr;
+    uint32_t *d_hand = nullptr;     // Params::hand_meta (stereo contexts of 4096-sample blocks with LPC; else nullptr)
     flacgpu_frame_plan *d_fplan = nullptr;
     uint32_t *d_stats_base = nullptr;   // Params::turn_counter words in front of d_stats (zeroed by the same memset)
     uint32_t *d_stats = nullptr;
@@ -518,6 +520,10 @@ static int create_impl(flacgpu_ctx *c, const flacgpu_options *o) {
     ALLOC(c->d_out, F * C);
     ALLOC(c->d_lpc, F * NC);
     ALLOC(c->d_finfo, F);
+    if (c->stereo4 && B == FN && o->max_lpc_order > 0 && !read_knobs().no_hand) {   // (c->knobs is filled further down)
+        ALLOC(c->d_hand, F * 2);
+        HIP_TRY(hipMemset(c->d_hand, 0, sizeof(uint32_t) * F * 2));
+    }
     ALLOC(c->d_fplan, F);
     // Params::turn_counter (4 words), counters, then the per-candidate ORs (one memset per batch over all three), then Params::defer_stats
     ALLOC(c->d_stats_base, kTurnWords + 4 + F * NC + kDeferWords + 16);
@@ -579,6 +585,7 @@ void flacgpu_destroy(flacgpu_ctx *c) {
     (void)hipFree(c->d_in); (void)hipFree(c->d_planar); (void)hipFree(c->d_resid); (void)hipFree(c->d_window_full);
     (void)hipFree(c->d_window_last); (void)hipFree(c->d_log2_thr); (void)hipFree(c->d_ac); (void)hipFree(c->d_cinfo);
     (void)hipFree(c->d_fixed); (void)hipFree(c->d_cand); (void)hipFree(c->d_out); (void)hipFree(c->d_lpc);
+    (void)hipFree(c->d_hand);
     (void)hipFree(c->d_finfo); (void)hipFree(c->d_fplan); (void)hipFree(c->d_stats_base);
     (void)hipFree(c->d_packed); (void)hipFree(c->d_frame_off); (void)hipFree(c->d_tile_sync);
     if (c->d_seg_fn) (void)hipFree(c->d_seg_fn);
@@ -665,6 +672,7 @@ static void fill_params(const flacgpu_ctx *c, uint32_t n_frames, uint32_t last_l
     p.defer_margin16 = c->knobs.defer_margin16 >= 0 ? (uint32_t)c->knobs.defer_margin16 : kDeferMargin16;
     p.defer_stats = defer_stats_of(c);   // behind the ORs; cumulative, zeroed at creation
     p.turn_counter = c->d_stats_base;
+    p.hand_meta = nullptr;   // (set by analyze_impl for the batches whose candidate kernel hands its residuals over)
 }
 
 // stream == NULL: the context's own (non-blocking) stream, ordered AFTER whatever the caller has
@@ -837,6 +845,9 @@ static int analyze_impl(flacgpu_ctx *c, const int32_t *d_pcm, int layout, uint32
     c->planar_valid = !direct;
     c->direct_src = direct ? d_pcm : nullptr;
     if (direct) p.inter = d_pcm;
+    // the winners' LPC residuals handed from k_cand64p to k_frame64 (Params::hand_meta): 4096-sample direct stereo frames with
+    // LPC -- the candidate kernel's instantiations that keep the frame's image through the turn
+    if (direct && B == FN && p.max_lpc_order > 0 && c->d_hand) p.hand_meta = c->d_hand;
     if (direct && c->seg_active && c->seg_direct) p.inter_tab = c->d_seg_ptr;   // (frames found through the table; d_pcm = the first segment)
     c->abs_valid = false;
     if (c->d_abs && first_range) HIP_TRY(hipMemsetAsync(c->d_abs, 0, sizeof(unsigned long long) * 4 * n_frames, st));
@@ -1086,6 +1097,9 @@ static int resolve_order_ties(flacgpu_ctx *c) {
 
 static int ensure_residual_rows(flacgpu_ctx *c) {
     if (c->resid_valid) return FLACGPU_OK;
+    // (the rows take the place of what the candidate kernel handed to k_frame64 -- Params::hand_meta --: a frame assembly that
+    // follows fetches its samples itself)
+    c->last_params.hand_meta = nullptr;
     if (int rc = ensure_planar(c)) return rc;   // k_emit reads planar rows
     if (int rc = ctx_sync(c)) return rc;
     const Params &p = c->last_params;
@@ -2365,6 +2379,26 @@ void *flacgpu_device_buffer(flacgpu_ctx *c, int which) {
     case 6: return c->d_ac;
     default: return nullptr;
     }
+}
+
+// Diagnostic: of the last batch's subframes, how many k_cand64p handed to k_frame64 with their residual (Params::hand_meta).
+// *enabled = 0 and zeros where the batch's shape has no hand-over (or FLACGPU_NO_HAND is set, or residual rows were fetched).
+int flacgpu_handed_subframes(flacgpu_ctx *c, uint32_t *handed, uint32_t *subframes, int *enabled) {
+    if (!c) return FLACGPU_ERR_INVALID_ARG;
+    CTX_GUARD(c);
+    if (int rc = ctx_sync(c)) return rc;
+    const bool on = c->last_frames && c->last_params.hand_meta;
+    uint32_t n = 0;
+    const uint32_t total = on ? c->last_frames * 2u : 0u;
+    if (on) {
+        std::vector<uint32_t> flags(total);
+        if (int rc = copy_sync(c, flags.data(), c->d_hand, sizeof(uint32_t) * total, hipMemcpyDeviceToHost)) return rc;
+        for (uint32_t v : flags) n += v ? 1u : 0u;
+    }
+    if (handed) *handed = n;
+    if (subframes) *subframes = total;
+    if (enabled) *enabled = on ? 1 : 0;
+    return FLACGPU_OK;
 }
 
 int flacgpu_get_kernel_ms(flacgpu_ctx *c, float ms[FLACGPU_N_KERNELS]) {

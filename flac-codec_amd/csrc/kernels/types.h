@@ -126,6 +126,15 @@ struct Params {
     // counters by the host, and again by whoever draws a launch's last ticket); launches of one context that may run
     // concurrently (the two ranges of FLACGPU_TUNE_TWO_RANGES) use different words
     uint32_t *turn_counter;
+    // THE RESIDUAL HANDED OVER (r06; 4096-sample direct stereo frames with LPC): the candidate wave that wins a subframe with its
+    // LPC candidate still holds that candidate's folded residual in registers when the channel choice is made -- t = r ^ (r >> 31)
+    // with r's sign kept in bit 31 (wave_rice_fold<SIGNS>): zigzag(r) rotated right by one.  It stores the 64 x 64 words into the
+    // subframe's row of Params::residuals (sample e of lane l at dword 256 (e / 4) + 4 l + e % 4: a contiguous kilobyte per
+    // instruction on both sides) and hand_meta[subframe] = 1; k_frame64 reads them back instead of fetching both channels, picking, shifting and
+    // running the FIR a second time.  nullptr: off (every other shape; plans that came from the host).  A subframe whose winner
+    // is FIXED / CONSTANT / VERBATIM, or whose wave had to re-fetch its samples for the exact FIXED count, gets 0 and takes
+    // k_frame64's own path.
+    uint32_t *hand_meta;   // [frame][2]
 };
 
 
@@ -207,6 +216,7 @@ struct Knobs {
          ac_eight_waves = false,   // A/B: k_autocorr4<13, 8> (FLACGPU_AC_WAVES8)
          cand_persist_n = false,   // A/B: persistent candidate kernel for independent channels (FLACGPU_CAND_PERSIST_N)
          early_download = false,   // the frames' D2H copy queued before the sizes are known (FLACGPU_EARLY_DOWNLOAD)
+         no_hand = false,          // A/B: Params::hand_meta off (FLACGPU_NO_HAND)
          no_direct_short = false,  // A/B: 1024 / 1152 / 2048 / 2304-sample blocks through K0 + k_cand64 (FLACGPU_NO_DIRECT_SHORT)
          lpc_fuse_deep = false,    // A/B: K4 in the tail of k_autocorr4_deep as well (FLACGPU_LPC_FUSE_DEEP; measured slower)
          no_ac_fma = false,        // A/B: every autocorrelation term a multiply and an add (FLACGPU_NO_AC_FMA)

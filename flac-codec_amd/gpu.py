@@ -349,6 +349,17 @@ class GpuAnalyzer:
             raise GpuError(rc, "flacgpu_get_stats")
         return s
 
+    def handed_subframes(self):
+        """(handed, subframes, enabled) of the last batch: subframes whose residual the candidate kernel handed to the frame
+        kernel (flacgpu_handed_subframes)"""
+        L = _lib.lib()
+        h, n, e = C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+        L.flacgpu_handed_subframes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        rc = L.flacgpu_handed_subframes(self._h, C.byref(h), C.byref(n), C.byref(e))
+        if rc:
+            raise GpuError(rc, "flacgpu_handed_subframes")
+        return h.value, n.value, bool(e.value)
+
     def set_timing(self, on=True):
         _lib.lib().flacgpu_set_timing(self._h, int(on))
 

@@ -191,6 +191,12 @@ int flacgpu_analyze_device(flacgpu_ctx *ctx, const int32_t *d_pcm, int layout, u
 int flacgpu_fetch(flacgpu_ctx *ctx, flacgpu_frame_plan *plans, flacgpu_subframe_plan *subframes,
                   int32_t *residuals);
 int flacgpu_get_stats(flacgpu_ctx *ctx, flacgpu_stats *out);
+/* Diagnostic (bench, tests): of the last batch's subframes, how many the candidate kernel handed to the frame kernel together
+ * with their residual -- 4096-sample stereo frames read in place, LPC on: the wave that wins a subframe with an LPC candidate
+ * stores the folded residual it still holds, and the frame kernel neither fetches the channels nor runs the FIR again
+ * (encode.rs:3174-3203 is evaluated once per winning subframe instead of twice).  *enabled = 0 where the batch's shape has no
+ * hand-over, FLACGPU_NO_HAND=1 is set, or the residual rows were fetched in between.  Synchronises the context. */
+int flacgpu_handed_subframes(flacgpu_ctx *ctx, uint32_t *handed, uint32_t *subframes, int *enabled);
 
 /* Device pointers of the last analysis (for callers that chain further device work):
  * which: 0 frame plans, 1 subframe plans, 2 residuals, 3 planar pcm, 4 packed frame bytes,
