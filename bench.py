@@ -683,6 +683,17 @@ class Workload:
         an.set_timing(False)
         return {k: v for k, v in acc.items() if v > 0}
 
+    def handed(self):
+        """What the candidate kernel hands to the frame kernel in one batch (flacgpu_handed_subframes of context 0's last
+        batch): subframes handed with their residual, bytes written for them."""
+        try:
+            h, n, on = self.ans[0].handed_subframes()
+        except Exception:
+            return None
+        if not on:
+            return {"enabled": False}
+        return {"enabled": True, "subframes": n, "handed": h, "frac": round(h / max(1, n), 4), "bytes_written": 4.0 * h * BLOCK}
+
     def algorithmic(self, compressed_bytes):
         """algorithmic bytes / flops per launch (DESIGN.md "Kernels")"""
         F, C = self.F, self.C
@@ -733,7 +744,7 @@ class Workload:
         self.d_pcm = None
 
 
-def roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale):
+def roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale, handed=None):
     """The `roofline` object of the dominant kernel, with the bound that prices it."""
     kind, amount = alg[dom]
     k = kernels[dom]
@@ -751,6 +762,16 @@ def roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale):
                      "(integer factors, exact product: identical rounding); 78.6 TFLOP/s is the stated f64 peak, 39.3 what "
                      "mul + add can reach"}
     r["avg_launch_ms"] = k["ms"]
+    if handed and handed.get("enabled") and dom == "k_cand64" and kind == "hbm":
+        # the candidate kernel also WRITES the winners' residuals for the frame kernel (r06): not counted in `achieved` /
+        # `frac`, which keep r05's definition (4 B per candidate sample read + the plans); SURVEY 8(d) prices the FIR stage
+        # at 4 B read + 4 B residual written, which is what the second figure adds for the handed subframes
+        with_res = (amount + handed["bytes_written"]) / (k["ms"] * 1e-3) / 1e9
+        r["handed_residuals"] = {"subframes": handed["subframes"], "handed": handed["handed"], "bytes_written": handed["bytes_written"],
+                                 "achieved_with_them_GB/s": round(with_res, 1), "frac_with_them": round(with_res / HBM_PEAK_GBS, 4),
+                                 "note": "k_cand64p stores the folded LPC residual of every subframe an LPC candidate wins and "
+                                         "k_frame64 reads it back instead of both channels (no second FIR); `achieved` and `frac` "
+                                         "above do NOT count these bytes"}
     r["dominance_rule"] = ("longest launch among the priced kernels (HBM bytes or f64 flops); launches within 3 % are tied, "
                            "an HBM-priced kernel wins a tie (every kernel's own fraction is in kernels.*)")
     r["counters_stale"] = stale
@@ -923,7 +944,7 @@ def measure_other_config(torch, cfg_id, args, device, orc, signal="ar2"):
            "frames_byte_identical_to_oracle": identical, "frames_checked": identical + differ,
            "frames_round_tripped_on_device": w.F * len(w.ans),
            "oracle_decisions": histogram_summary(w, cfg_id),
-           "dominant_kernel": roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale),
+           "dominant_kernel": roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale, w.handed()),
            "fixed_count": {"decided_by_bound": st0.fixed_decided, "refetched": st0.fixed_refetched,
                            "note": "candidates of context 0 since it was created whose exact FIXED bit count was put off "
                                    "behind the LPC half (Params::defer_fixed): skipped / counted after a re-fetch"},
@@ -965,6 +986,10 @@ def compact_record(out, detail_path=None):
         v = r.get("valu_issue") or {}
         if v.get("frac_of_attainable") is not None:
             rec["roofline"]["frac_of_issue_floor"] = v["frac_of_attainable"]
+        h = r.get("handed_residuals")
+        if h:   # (bytes the kernel also writes for the frame kernel: NOT in `achieved` / `frac`)
+            rec["roofline"]["handed_residual_bytes"] = h["bytes_written"]
+            rec["roofline"]["frac_with_handed_residuals"] = h["frac_with_them"]
     else:
         rec["roofline"] = None
     c = out.get("cpu_baseline")
@@ -1410,7 +1435,7 @@ def main():
         traffic = traffic_src = valu = stale = None
         if F == FRAMES:
             traffic, traffic_src, valu, stale = profile_figures(args.config, dom, kernels[dom]["ms"], args.signal)
-        roofline = roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale)
+        roofline = roofline_of(kernels, dom, alg, traffic, traffic_src, valu, stale, w.handed())
         headline_decisions = histogram_summary(w, args.config)
 
         cpu = None
