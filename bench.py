@@ -406,6 +406,10 @@ def end_to_end(cfg, pcm, device, orc, batch_frames=0):
         "coalesced_frac_of_link": round(rate_of(n_small, f_small, co_dt) / link_limit, 4),
         "stream_length_sweep": sweep,
         "coalesced_wins_at_every_length": all(r["coalesced_Msamples/s"] >= r["per_stream_writers_Msamples/s"] for r in sweep),
+        # (where a few dozen long streams' MD5 chains bound both front ends -- 16 x 512, 32 x 256, 64 x 512 -- the two are the
+        # same speed and the strict comparison is decided by the run's noise)
+        "coalesced_at_least_0.97_of_the_writers_at_every_length":
+            all(r["coalesced_Msamples/s"] >= 0.97 * r["per_stream_writers_Msamples/s"] for r in sweep),
         "byte_identical": True,
         "note": "flacenc_encode_many_coalesced against flacenc_encode_many, host PCM -> .flac bytes, MD5 included, bytes "
                 "compared at every length (one stream with the oracle); the sweep's rows: both front ends' calls in three alternating "
