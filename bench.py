@@ -1246,7 +1246,7 @@ def in_process(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)   # (36 ms of timed region at the headline workload; the sustained leg runs 200 more)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (SURVEY.md 8(d)); 3 is the headline metric")

@@ -40,7 +40,7 @@ def main():
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     rc = hip.hipMemcpy(rows.data_ptr(), an.device_buffer(6), rows.numel() * 8, 3)
     assert rc == 0, rc
-    t = rows.cpu().numpy().reshape(F, NC, 36)[:, :2, :6]
+    t = rows.cpu().numpy().reshape(F, NC, 36)[:, :2, :9]
     st = t.astype(np.float64) * 0.01
     res = {"signal": a.signal, "config": a.config}
 
@@ -50,6 +50,11 @@ def main():
         res[name] = r
 
     q("0-1 zero the image, tables, header", st[:, :, 1] - st[:, :, 0])
+    if st[:, :, 6].max() > 0:   # (r06: stamps inside the preparation)
+        q("  0-6 scalars in, the wave's loads requested", st[:, :, 6] - st[:, :, 0])
+        q("  6-7 image zeroed", st[:, :, 7] - st[:, :, 6])
+        q("  7-8 table piece stored, the two waves met", st[:, :, 8] - st[:, :, 7])
+        q("  8-1 frame header", st[:, :, 1] - st[:, :, 8])
     q("1-2 plan + samples, residual, Rice emission", st[:, :, 2] - st[:, :, 1])
     q("2-3 barrier (the other subframe)", st[:, :, 3] - st[:, :, 2])
     q("3-4 CRC-16", st[:, :, 4] - st[:, :, 3])
