@@ -1270,8 +1270,8 @@ def main():
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of every other_configs entry")
     ap.add_argument("--e2e-batch-frames", type=int, default=0,
                     help="batch_frames of the writers in the end_to_end block (0: the library default)")
-    ap.add_argument("--contexts", type=int, default=4, choices=(1, 2, 3, 4, 5, 6),
-                    help="encoder contexts consecutive batches rotate through (multi-buffering)")
+    ap.add_argument("--contexts", type=int, default=3, choices=(1, 2, 3, 4, 5, 6),
+                    help="encoder contexts consecutive batches rotate through (multi-buffering; r06: three -- with the hand-over four are 1 %% slower, profiles/r06_contexts.json)")
     ap.add_argument("--lag-split", type=int, default=0, choices=(0, 2, 4),
                     help="waves the autocorrelation lags are split over (0: the library default)")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
