@@ -97,6 +97,62 @@ def make_pcm(seed, frames, channels, bps, signal="ar2", sections=6):
     return np.tile(base, reps)[: frames * BLOCK * channels]
 
 
+class GpuSensors:
+    """The shader clock and the socket power of the GPU this rank runs on, read from its hwmon files while a timed loop runs
+    (amdgpu: freq1_input in Hz, power1_input in uW, power1_cap).  The boxes of the pool do not all clock alike -- one met in r06
+    holds 2.13-2.16 GHz under this load where the others hold 2.3-2.4 -- and `value` moves with it."""
+
+    def __init__(self, torch, device):
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            import glob
+            for d in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % want):
+                if os.path.exists(os.path.join(d, "freq1_input")):
+                    self.dir = d
+        except Exception:
+            self.dir = None
+        self.samples = []
+        self._stop = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def start(self, period=0.004):
+        if not self.dir:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                f, pw = self._read("freq1_input"), self._read("power1_input")
+                if f and pw:
+                    self.samples.append((f / 1e6, pw / 1e6))
+                self._stop.wait(period)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if not self._stop:
+            return None
+        self._stop.set()
+        self._th.join()
+        if not self.samples:
+            return None
+        fs = [a for a, _ in self.samples]
+        ps = [b for _, b in self.samples]
+        cap = self._read("power1_cap")
+        return {"sclk_MHz": round(statistics.median(fs)), "sclk_MHz_min_max": [round(min(fs)), round(max(fs))],
+                "socket_power_W": round(statistics.median(ps)), "power_cap_W": round(cap / 1e6) if cap else None,
+                "samples": len(fs), "source": "hwmon freq1_input / power1_input of the rank's GPU during the sustained loop"}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -1009,6 +1065,10 @@ def compact_record(out, detail_path=None):
               "compression_ratio": out.get("compression_ratio"), "experiment": out.get("experiment")}
     if out.get("sustained"):
         extras["sustained_ms_per_step"] = out["sustained"]["ms_per_step"]
+        ck = out["sustained"].get("gpu_clock")
+        if ck:   # (the pool's boxes do not clock alike: `value` moves with this)
+            extras["sclk_MHz"] = ck["sclk_MHz"]
+            extras["socket_power_W"] = ck["socket_power_W"]
     var = out.get("variants") or {}
     if var.get("one_context_back_to_back"):
         extras["one_context_ms_per_step"] = var["one_context_back_to_back"]["ms_per_step"]
@@ -1359,9 +1419,14 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     sustained = None
     if args.sustained_steps > 0:
+        sensors = GpuSensors(torch, local_rank)
+        sensors.start()
         el = w.timed(args.sustained_steps, dist)
+        clock = sensors.stop()
         sustained = {"steps": args.sustained_steps, "ms_per_step": round(el / args.sustained_steps * 1e3, 4),
                      "value": round(samples_per_step * args.sustained_steps / el / 1e6, 2), "unit": "Msamples/s"}
+        if clock:
+            sustained["gpu_clock"] = clock
     # A/B of the input buffers and of the context count (same run, same clocks)
     variants = {}
     if not strong and len(w.ans) > 1:
